@@ -1,0 +1,177 @@
+/* pdlp_hip.h -- C ABI of libpdlp_hip.so: the restarted-PDHG hot path for AMD Instinct MI355X (gfx950).
+ *
+ * Drop-in boundary for SimplySnap/torchPDLP's solver hot path.  The reference has no FFI; its
+ * boundary is the set of Python functions pdlp_algorithm() calls.  Each
+ * entry point below names the reference function (file:line under /root/reference) whose
+ * arithmetic it replaces.  All pointers in pdlp_problem and the workspace are DEVICE pointers
+ * (e.g. torch.Tensor.data_ptr()); the library never allocates or frees device memory, never
+ * copies the problem data, and enqueues all work on the HIP stream given at creation.
+ *
+ * LP form (reference PDLP/util.py:76-84):
+ *     min c'x  s.t.  K[:m_ineq] x >= q[:m_ineq],  K[m_ineq:] x = q[m_ineq:],  l <= x <= u
+ *
+ * Layout: K is held twice, as CSR of K (rows = constraints) and CSR of K' (rows = variables),
+ * int32 row pointers / column indices, values in the working precision.  One process per GPU:
+ * a rank owns rows [row0,row1) of K (with y, q) and rows [col0,col1) of K' (with x, c, l, u);
+ * vectors that are gathered from (x, xbar, y and their averaged copies) live in full-length
+ * buffers which the caller all-gathers between the half-steps (single GPU: the block is the
+ * whole range and no exchange is needed).
+ *
+ * Every function returns PDLP_OK (0) or a negative error code (pdlp_strerror()).
+ * A handle is not thread-safe; use one handle per GPU rank.
+ */
+#ifndef PDLP_HIP_H
+#define PDLP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDLP_OK 0
+#define PDLP_ERR_INVALID (-1)      /* bad argument / inconsistent sizes            */
+#define PDLP_ERR_WORKSPACE (-2)    /* workspace too small or misaligned            */
+#define PDLP_ERR_STATE (-3)        /* call sequence violated                       */
+#define PDLP_ERR_HIP_BASE (-1000)  /* -(1000 + hipError_t) for HIP runtime errors  */
+
+enum { PDLP_F32 = 0, PDLP_F64 = 1 };
+
+/* which iterate an evaluation refers to (reference pdhg.py:118-125) */
+enum { PDLP_CUR = 0, PDLP_AVG = 1, PDLP_PREV = 2 };
+
+/* device buffers the caller may need to view (collectives, reading results) */
+enum {
+    PDLP_BUF_X_CUR = 0, PDLP_BUF_X_PREV = 1, PDLP_BUF_XBAR = 2, PDLP_BUF_X_AVG = 3,     /* full length n */
+    PDLP_BUF_Y_CUR = 4, PDLP_BUF_Y_PREV = 5, PDLP_BUF_Y_AVG = 6,                       /* full length m */
+    PDLP_BUF_RED = 7,        /* double[PDLP_NRED]: partial sums awaiting a cross-rank all-reduce          */
+    PDLP_BUF_X_SUM = 8, PDLP_BUF_Y_SUM = 9,   /* local length: eta-weighted sums (pdhg.py:107-108)         */
+    PDLP_BUF_SCALARS = 10    /* double[PDLP_NSCAL]: eta, omega, theta, tau, sigma, w_pending, eta_sum, k  */
+};
+#define PDLP_NRED 8
+#define PDLP_NSCAL 16
+
+typedef struct pdlp_problem {
+    int32_t dtype;              /* PDLP_F32 | PDLP_F64: precision of every vector and matrix value          */
+    int32_t device;             /* HIP device ordinal                                                       */
+    int64_t m, n;               /* global constraint / variable counts                                      */
+    int64_t m_ineq;             /* the first m_ineq constraints are ">=" rows (util.py:250-261)             */
+    int64_t row0, row1;         /* this rank's rows of K   (0,m on a single GPU)                            */
+    int64_t col0, col1;         /* this rank's rows of K'  (0,n on a single GPU)                            */
+    const int32_t* K_rowptr;    /* [row1-row0+1], K_rowptr[0] == 0                                          */
+    const int32_t* K_colidx;    /* [nnz_K]  global column indices in [0,n)                                  */
+    const void* K_val;          /* [nnz_K]                                                                  */
+    const int32_t* KT_rowptr;   /* [col1-col0+1]                                                            */
+    const int32_t* KT_colidx;   /* [nnz_KT] global row indices in [0,m)                                     */
+    const void* KT_val;         /* [nnz_KT]                                                                 */
+    const void* c;              /* [col1-col0]                                                              */
+    const void* l;              /* [col1-col0]  -inf allowed                                                */
+    const void* u;              /* [col1-col0]  +inf allowed                                                */
+    const void* q;              /* [row1-row0]                                                              */
+    const void* d_col;          /* [col1-col0] Ruiz column scaling or NULL (pdhg.py:157-161)                */
+    const void* d_row;          /* [row1-row0] Ruiz row scaling or NULL                                     */
+    void* stream;               /* hipStream_t all work is enqueued on (0 = null stream)                    */
+} pdlp_problem;
+
+typedef struct pdlp_solver* pdlp_handle;
+
+const char* pdlp_strerror(int code);
+/* library ABI version; bumped on any signature change */
+int pdlp_abi_version(void);
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+/* bytes of device workspace pdlp_create needs for this problem (state vectors + scratch) */
+int pdlp_workspace_bytes(const pdlp_problem* p, int64_t* bytes);
+/* Builds the row-block schedule of both CSR copies (reads the two row-pointer arrays back to the
+ * host once) and carves the caller's workspace (256-byte aligned device memory).  x = y = 0. */
+int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_t workspace_bytes);
+void pdlp_destroy(pdlp_handle h);
+/* device address of one of the PDLP_BUF_* buffers (inside the workspace) */
+int pdlp_buffer_ptr(pdlp_handle h, int which, void** ptr);
+
+/* ---- state ---------------------------------------------------------------------------------- */
+/* Copies this rank's block of the iterate from device memory (x: col1-col0, y: row1-row0 values)
+ * and zeroes the averaging sums.  Replaces the x/y initialisation of pdhg.py:31-36. */
+int pdlp_set_iterate(pdlp_handle h, const void* x_local, const void* y_local);
+int pdlp_get_iterate(pdlp_handle h, int which, void* x_local, void* y_local);   /* device destinations */
+/* step size eta, primal weight omega, extrapolation theta (pdhg.py:22-25); rounded to the working
+ * precision on the device exactly as the reference's 0-dim tensors are. iteration = global k so far. */
+int pdlp_set_step(pdlp_handle h, double eta, double omega, double theta, int64_t iteration);
+/* new primal weight after a restart (primal_weight_update enhancements.py:77); keeps the device eta */
+int pdlp_set_omega(pdlp_handle h, double omega);
+/* host copy of {eta, omega, theta, tau, sigma, w_pending, eta_sum, k} (synchronises the stream) */
+int pdlp_get_scalars(pdlp_handle h, double out[PDLP_NSCAL]);
+
+/* ---- the PDHG iteration --------------------------------------------------------------------- */
+/* primal half-step: x+ = clamp(x - (eta/omega)(c - K'y), l, u); xbar = x+ + theta(x+ - x)
+ * -- fixed_one_step_pdhg step.py:25-30 / adaptive_one_step_pdhg step.py:74-82 -- as ONE kernel:
+ * CSR(K') SpMV with the projection, extrapolation and eta-weighted sum fused into its epilogue.
+ * Needs y (PDLP_BUF_Y_CUR) complete over [0,m). Writes this rank's block of x+ and xbar. */
+int pdlp_primal_half(pdlp_handle h, int adaptive);
+/* dual half-step: y+ = y + eta*omega (q - K xbar); y+[:m_ineq] = max(.,0) -- step.py:33-38 / :85-90 --
+ * CSR(K) SpMV with the projection and sums fused.  Needs xbar complete over [0,n).  Afterwards
+ * the new iterate becomes PDLP_CUR and the old one PDLP_PREV (pdhg.py:77-78). */
+int pdlp_dual_half(pdlp_handle h, int adaptive);
+/* adaptive rule, part 1: reduce this rank's ||dx||^2, ||dy||^2, dy'K dx into PDLP_BUF_RED[0..2]
+ * (all-reduce them across ranks before part 2) -- step.py:91-96 */
+int pdlp_adaptive_reduce(pdlp_handle h);
+/* adaptive rule, part 2: eta_bar, eta', accept/reject, eta <- eta', weight of this iterate in the
+ * average, k <- k+1 -- step.py:99-115 incl. the single-trial quirk, pdhg.py:107-112 */
+int pdlp_adaptive_update(pdlp_handle h);
+/* `iters` whole iterations without host synchronisation (single-rank problems only):
+ * primal half, dual half and, when adaptive, the step-size rule.  pdhg.py:76-112 */
+int pdlp_iterate(pdlp_handle h, int iters, int adaptive);
+/* fixed step, multi-rank driver: eta_total += eta and k += 1, `iters` times (pdhg.py:76,109);
+ * pdlp_iterate does this itself */
+int pdlp_fixed_advance(pdlp_handle h, int iters);
+
+/* ---- restart machinery ---------------------------------------------------------------------- */
+/* adds the not-yet-accumulated weight of the current iterate to the sums (adaptive mode defers
+ * it by one step because the weight is only known after the step-size rule) */
+int pdlp_flush_average(pdlp_handle h);
+/* x_avg = x_sum / eta_sum, y_avg = y_sum / eta_sum for this rank's block -- pdhg.py:118-119 */
+int pdlp_compute_average(pdlp_handle h);
+/* KKT pass at PDLP_CUR / PDLP_AVG / PDLP_PREV: two fused SpMV kernels accumulate
+ * {dual_res^2, l_dual'max(lam,0), u_dual'min(lam,0), c'x, primal_res^2, q'y} of this rank's block
+ * into PDLP_BUF_RED[0..5] -- compute_residuals_and_duality_gap helpers.py:53-96 with
+ * project_lambda_box helpers.py:3-39.  unscaled != 0 evaluates the un-preconditioned problem
+ * (needs d_col/d_row) -- pdhg.py:157-161.  The x and y of `which` must be complete (all-gathered). */
+int pdlp_kkt_local(pdlp_handle h, int which, int unscaled);
+/* reads PDLP_BUF_RED (after the caller's all-reduce), returns
+ * {primal_residual, dual_residual, duality_gap (signed), prim_obj, adjusted_dual, KKT_error}
+ * -- helpers.py:84-94, KKT_error helpers.py:98-108.  Synchronises the stream. */
+int pdlp_kkt_finish(pdlp_handle h, double omega, double out[6]);
+/* make PDLP_AVG (or keep PDLP_CUR) the current iterate and zero the sums -- pdhg.py:57-60,131-142 */
+int pdlp_restart(pdlp_handle h, int which);
+/* ||x - x_last_restart||^2, ||y - y_last_restart||^2 of this rank's block into PDLP_BUF_RED[0..1]
+ * -- primal_weight_update enhancements.py:74-75; pdlp_restart keeps the previous restart point,
+ * so call this after it and before pdlp_mark_restart_point */
+int pdlp_restart_distance_local(pdlp_handle h);
+/* x_last_restart, y_last_restart <- current iterate -- pdhg.py:63-64 */
+int pdlp_mark_restart_point(pdlp_handle h);
+int pdlp_read_red(pdlp_handle h, double out[PDLP_NRED]);   /* synchronises the stream */
+
+/* ---- plain products (power iteration helpers.py:41-51, tests) ------------------------------- */
+/* out_local = K in_full (transpose=0, out has row1-row0 values) or K' in_full (transpose=1) */
+int pdlp_spmv(pdlp_handle h, int transpose, const void* in_full, void* out_local);
+/* spectral_norm_estimate_torch helpers.py:41-51 with the start vector given (single rank) */
+int pdlp_power_iteration(pdlp_handle h, const void* b0, int iters, void* work_n, void* work_m, double* sigma);
+
+/* ---- Ruiz equilibration on CSR (ruiz_precondition enhancements.py:4-71) ---------------------- */
+/* norm[i] = sqrt(max_p |val[p]|) over row i, replaced by 1 when < eps (:49-50 / :54-55) */
+int pdlp_csr_row_scale_factors(int dtype, int64_t rows, const int32_t* rowptr, const void* val, double eps,
+                               void* norm, void* stream);
+/* val[p] /= norm[row(p)]                      (:52 / :57 on the copy whose rows are being scaled) */
+int pdlp_csr_div_rows(int dtype, int64_t rows, const int32_t* rowptr, void* val, const void* norm, void* stream);
+/* val[p] /= norm_full[colidx[p]]              (the same scaling applied to the transposed copy)   */
+int pdlp_csr_div_cols(int dtype, int64_t rows, const int32_t* rowptr, const int32_t* colidx, void* val,
+                      const void* norm_full, void* stream);
+/* elementwise helpers for D /= norm, c*D, l/D ... (:51,:56,:64-67); op: 0 a*=b, 1 a/=b */
+int pdlp_vec_muldiv(int dtype, int64_t len, void* a, const void* b, int op, void* stream);
+/* max_i |1 - v[i]| (the early-exit test :60-61); host result, synchronises */
+int pdlp_vec_max_dev_from_one(int dtype, int64_t len, const void* v, void* work8, double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDLP_HIP_H */

@@ -1,0 +1,416 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the reference's golden vectors.
+
+float32 like the reference.  Tolerances cover summation order only (the GPU reduces rows with up
+to 64 lanes and norms in float64): single operators 2e-5 relative, 40 chained steps 1e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as orc                                   # the checker (tests only)
+import torchpdlp_amd as tp
+from torchpdlp_amd import _native as N
+from torchpdlp_amd.synthetic import gen_lp
+
+LP_CASES = ["mixed_27x32", "mixed_400x300", "mixed_300x400_alleq", "mixed_200x260_allineq", "box_200x150"]
+DEV = "cuda:0"
+
+
+def close(a, b, rtol):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    a, b = np.asarray(a, np.float64).reshape(-1), np.asarray(b, np.float64).reshape(-1)
+    atol = rtol * max(1.0, float(np.max(np.abs(b))) if b.size else 1.0)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def golden_lp(g, name, dtype=torch.float32):
+    a = g.group(name)
+    t = lambda v, dt=dtype: torch.tensor(np.asarray(v), dtype=dt, device=DEV)
+    K = tp.CsrPair(int(a["m"]), int(a["n"]), t(a["rowptr"], torch.int32), t(a["colidx"], torch.int32), t(a["val"]))
+    o = orc.OracleLP(a["m"], a["n"], a["m_ineq"], a["rowptr"], a["colidx"], a["val"], a["c"], a["q"], a["l"], a["u"],
+                     dtype=np.float32 if dtype == torch.float32 else np.float64)
+    eng = tp.PdlpEngine.from_full(K, t(a["c"]), t(a["q"]), t(a["l"]), t(a["u"]), int(a["m_ineq"]))
+    return a, K, o, eng
+
+
+def dev(v, dtype=torch.float32):
+    return torch.tensor(np.asarray(v), dtype=dtype, device=DEV)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _setup():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    orc.set_threads(1)
+    N.load()
+
+
+# ---------------------------------------------------------------------------------------------------
+# plain products, incl. the row shapes the schedule treats differently
+# ---------------------------------------------------------------------------------------------------
+def _random_csr(m, n, lens, seed):
+    rng = np.random.default_rng(seed)
+    rp = np.zeros(m + 1, np.int32)
+    rp[1:] = np.cumsum(lens)
+    ci = np.concatenate([np.sort(rng.choice(n, size=k, replace=False)) for k in lens]).astype(np.int32) if rp[-1] else np.zeros(0, np.int32)
+    va = rng.standard_normal(rp[-1]).astype(np.float32)
+    return rp, ci, va
+
+
+@pytest.mark.parametrize("shape", ["short", "empty_rows", "long_rows", "ragged", "one_row", "wide100"])
+def test_spmv_matches_oracle(shape):
+    rng = np.random.default_rng(3)
+    if shape == "short":
+        m, n = 5000, 3000
+        lens = rng.integers(1, 9, m)
+    elif shape == "empty_rows":
+        m, n = 3000, 500
+        lens = rng.integers(0, 3, m)
+        lens[:300] = 0
+        lens[-7:] = 0
+    elif shape == "long_rows":          # rows above the 2048-nnz LDS cap take the whole-workgroup path
+        m, n = 40, 9000
+        lens = rng.integers(1, 30, m)
+        lens[[0, 17, 39]] = [5000, 2049, 8999]
+    elif shape == "ragged":
+        m, n = 2000, 4000
+        lens = (rng.pareto(1.2, m) * 3).astype(np.int64).clip(0, 3500)
+    elif shape == "one_row":
+        m, n = 1, 10
+        lens = np.array([4])
+    else:                               # ~100 nnz per row: 20 rows per block, 8 lanes per row
+        m, n = 3000, 20000
+        lens = rng.integers(90, 111, m)
+    rp, ci, va = _random_csr(m, n, lens, 5)
+    z = np.zeros
+    o = orc.OracleLP(m, n, 0, rp, ci, va, z(n), z(m), z(n), z(n))
+    K = tp.CsrPair(m, n, dev(rp, torch.int32), dev(ci, torch.int32), dev(va))
+    eng = tp.PdlpEngine.from_full(K, dev(z(n)), dev(z(m)), dev(z(n)), dev(z(n)), 0)
+    x = rng.standard_normal(n).astype(np.float32)
+    y = rng.standard_normal(m).astype(np.float32)
+    close(eng.spmv(dev(x), False), o.spmv(x, False), 2e-5)
+    close(eng.spmv(dev(y), True), o.spmv(y, True), 2e-5)
+    # the transposed copy built on the device equals scipy's
+    np.testing.assert_array_equal(K.t_rowptr.cpu().numpy(), o.trp)
+    np.testing.assert_array_equal(K.t_colidx.cpu().numpy(), o.tci)
+
+
+# ---------------------------------------------------------------------------------------------------
+# one PDHG step
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", LP_CASES)
+def test_step_fixed_vs_golden_and_oracle(golden, name):
+    g = golden("step_fixed.npz")
+    a, K, o, eng = golden_lp(g, name)
+    eng.set_iterate(dev(a["x0"]), dev(a["y0"]))
+    eng.set_step(float(a["eta"]), float(a["omega"]), float(a["theta"]), 0)
+    xo, yo = a["x0"], a["y0"]
+    done = 0
+    for it in (1, 2, 40):
+        eng.iterate(it - done, False)
+        for _ in range(it - done):
+            xo, yo = o.step_fixed(xo, yo, a["eta"], a["omega"], a["theta"])
+        done = it
+        x, y = eng.get_iterate(N.CUR)
+        close(x, a[f"x{it}"], 2e-6 * it + 1e-6)       # the reference's own output
+        close(y, a[f"y{it}"], 2e-6 * it + 1e-6)
+        close(x, xo, 2e-6 * it + 1e-6)                 # the oracle
+        close(y, yo, 2e-6 * it + 1e-6)
+    # running sums of the 40 steps: eta_total and the eta-weighted average (pdhg.py:107-109)
+    s = eng.scalars()
+    np.testing.assert_allclose(s["eta_sum"], 40 * float(a["eta"]), rtol=1e-5)
+    assert s["k"] == 40
+    xp, yp = eng.get_iterate(N.PREV)                    # the iterate before the last step (pdhg.py:77-78)
+    assert float((xp - x).abs().max()) > 0
+
+
+def test_reference_named_ops(golden):
+    """the drop-in functions under the reference's names and argument order"""
+    g = golden("step_fixed.npz")
+    a, K, o, eng = golden_lp(g, "mixed_400x300")
+    col = lambda v: dev(v).view(-1, 1)
+    c, q, l, u = col(a["c"]), col(a["q"]), col(a["l"]), col(a["u"])
+    y = col(a["y0"])
+    x1, y1, e1, e2 = tp.fixed_one_step_pdhg(col(a["x0"]), y, c, q, K, l, u, int(a["m_ineq"]), dev(a["eta"]), dev(a["omega"]), 1.0)
+    assert x1.shape == (300, 1) and y1.shape == (400, 1) and e1 is e2
+    close(x1, a["x1"], 3e-6)
+    close(y1, a["y1"], 3e-6)
+    close(y, a["y1"], 3e-6)                               # y updated in place like step.py:34-38
+    # dense and COO inputs, as the reference takes them
+    Kd = K.to_dense()
+    for Kin in (Kd, Kd.to_sparse()):
+        x1b, y1b, _, _ = tp.fixed_one_step_pdhg(col(a["x0"]), col(a["y0"]), c, q, Kin, l, u, int(a["m_ineq"]), a["eta"], a["omega"], 1.0)
+        close(x1b, a["x1"], 3e-6)
+        close(y1b, a["y1"], 3e-6)
+    ga = golden("step_adaptive.npz")
+    r = ga.group("mixed_400x300/accept")
+    b = ga.group("mixed_400x300")
+    xa, ya, eu, eh, j = tp.adaptive_one_step_pdhg(col(b["x0"]), col(b["y0"]), c, q, K, l, u, int(a["m_ineq"]), dev(r["eta_in"]),
+                                                 dev(b["omega"]), 1.0, int(r["k"]), 3)
+    assert j == 4
+    close(xa, r["x1"], 3e-6)
+    np.testing.assert_allclose(float(eh), float(r["eta_hat"]), rtol=2e-5)
+    gk = golden("kkt.npz")
+    rk = gk.group("mixed_400x300/rand")
+    pr, dr, gap, p, dadj = tp.compute_residuals_and_duality_gap(col(rk["x"]), col(rk["y"]), c, q, K, int(a["m_ineq"]), l=l, u=u)
+    np.testing.assert_allclose(float(pr), float(rk["pr"][0]), rtol=2e-5)
+    np.testing.assert_allclose(float(dr), float(rk["dr"][0]), rtol=2e-5)
+    kk = tp.KKT_error(col(rk["x"]), col(rk["y"]), c, q, K, int(a["m_ineq"]), dev(rk["omega"]), l=l, u=u)
+    np.testing.assert_allclose(float(kk), float(rk["kkt"][0]), rtol=2e-5)
+    # the reference's mask-based calling convention
+    inn, ipn = torch.isinf(l) & (l < 0), torch.isinf(u) & (u > 0)
+    ld, ud = l.clone(), u.clone()
+    ld[inn], ud[ipn] = 0, 0
+    kk2 = tp.KKT_error(col(rk["x"]), col(rk["y"]), c, q, K, int(a["m_ineq"]), dev(rk["omega"]), inn, ipn, ld, ud, DEV)
+    assert float(kk2) == float(kk)
+
+
+@pytest.mark.parametrize("name", LP_CASES)
+@pytest.mark.parametrize("tag", ["accept", "reject", "late"])
+def test_step_adaptive_vs_golden(golden, name, tag):
+    g = golden("step_adaptive.npz")
+    a, K, o, eng = golden_lp(g, name)
+    r = g.group(f"{name}/{tag}")
+    eng.set_iterate(dev(a["x0"]), dev(a["y0"]))
+    eng.set_step(float(r["eta_in"]), float(a["omega"]), float(a["theta"]), int(r["k"]) - 1)
+    eng.iterate(1, True)
+    x, y = eng.get_iterate(N.CUR)
+    s = eng.scalars()
+    close(x, r["x1"], 3e-6)
+    close(y, r["y1"], 3e-6)
+    np.testing.assert_allclose(s["w_pending"], float(r["eta_used"]), rtol=3e-5)     # first returned step
+    np.testing.assert_allclose(s["eta"], float(r["eta_hat"]), rtol=3e-5)            # second returned step
+    assert bool(s["accepted"]) == bool(r["eta_used"] == r["eta_in"])
+    assert s["k"] == int(r["k"])
+    # oracle on the same input agrees on the internals of the rule
+    _, _, _, _, info = o.step_adaptive(a["x0"], a["y0"], r["eta_in"], a["omega"], a["theta"], r["k"])
+    np.testing.assert_allclose(s["denominator"], info["denominator"], rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(s["eta_bar"], info["eta_bar"], rtol=2e-4)
+
+
+@pytest.mark.parametrize("name", LP_CASES)
+def test_step_adaptive_chain(golden, name):
+    """12 chained adaptive steps: step sizes, the deferred average weights and the cached K x"""
+    g = golden("step_adaptive.npz")
+    a, K, o, eng = golden_lp(g, name)
+    r = g.group(f"{name}/chain")
+    eng.set_iterate(dev(a["x0"]), dev(a["y0"]))
+    eng.set_step(float(r["eta_in"]), float(a["omega"]), 1.0, 0)
+    ws, etas = [], []
+    for _ in range(12):
+        eng.iterate(1, True)
+        s = eng.scalars()
+        ws.append(s["w_pending"])
+        etas.append(s["eta"])
+    np.testing.assert_allclose(ws, r["weights"], rtol=2e-4)
+    np.testing.assert_allclose(etas, r["etas"], rtol=2e-4)
+    x, y = eng.get_iterate(N.CUR)
+    close(x, r["x12"], 2e-4)
+    close(y, r["y12"], 2e-4)
+    # averaged iterate = sum_k w_k x_k / sum_k w_k, with the last weight still pending before the flush
+    xo, yo, eta = a["x0"], a["y0"], np.float32(r["eta_in"])
+    xs, ys, wsum = np.zeros(o.n), np.zeros(o.m), 0.0
+    for k in range(1, 13):
+        xo, yo, w, eta, _ = o.step_adaptive(xo, yo, eta, a["omega"], 1.0, k)
+        xs += float(w) * xo
+        ys += float(w) * yo
+        wsum += float(w)
+    eng.flush_average()
+    eng.compute_average()
+    close(eng.buffer(N.BUF_X_AVG), xs / wsum, 3e-4)
+    close(eng.buffer(N.BUF_Y_AVG), ys / wsum, 3e-4)
+    np.testing.assert_allclose(eng.scalars()["eta_sum"], wsum, rtol=2e-4)
+
+
+def test_step_adaptive_zero_denominator(golden):
+    g = golden("step_adaptive.npz")
+    r = g.group("denzero")
+    K = tp.CsrPair.from_dense(dev(r["K"]))
+    eng = tp.PdlpEngine.from_full(K, dev(r["c"]), dev(r["q"]), dev(r["l"]), dev(r["u"]), int(r["m_ineq"]))
+    eng.set_iterate(torch.zeros(K.n, device=DEV), torch.zeros(K.m, device=DEV))
+    eng.set_step(float(r["eta_in"]), float(r["omega"]), 1.0, int(r["k"]) - 1)
+    eng.iterate(1, True)
+    s = eng.scalars()
+    x, y = eng.get_iterate(N.CUR)
+    assert s["denominator"] == 0.0 and np.isinf(s["eta_bar"]) and s["accepted"] == 1.0
+    close(x, r["x1"], 1e-6)
+    close(y, r["y1"], 1e-6)
+    np.testing.assert_allclose(s["eta"], float(r["eta_hat"]), rtol=1e-6)
+    np.testing.assert_allclose(s["w_pending"], float(r["eta_used"]), rtol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------
+# KKT residuals, primal weight, power iteration
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", LP_CASES)
+def test_kkt_vs_golden(golden, name):
+    g = golden("kkt.npz")
+    a, K, o, eng = golden_lp(g, name)
+    tags = sorted({c.split("/")[1] for c in g.cases(2) if c.startswith(name + "/")} & {"rand", "zero", "feas", "opt"})
+    for tag in tags:
+        r = g.group(f"{name}/{tag}")
+        eng.set_iterate(dev(r["x"]), dev(r["y"]))
+        out = eng.kkt(N.CUR, float(r["omega"]))
+        ref = o.kkt(r["x"], r["y"], r["omega"])
+        scale = max(1.0, abs(float(r["p"][0])), abs(float(r["d_adj"][0])))
+        for key in ("pr", "dr", "p", "d_adj", "kkt", "gap"):
+            tol = 4e-6 if key == "gap" else 2e-5
+            np.testing.assert_allclose(out[key], r[key][0], rtol=2e-5, atol=tol * scale, err_msg=f"golden {tag}:{key}")
+            np.testing.assert_allclose(out[key], float(ref[key]), rtol=2e-5, atol=tol * scale, err_msg=f"oracle {tag}:{key}")
+
+
+def test_primal_weight(golden):
+    g = golden("primal_weight.npz")
+    for case in g.cases(1):
+        r = g.group(case)
+        w = tp.primal_weight_update(dev(r["x_prev"]), dev(r["x"]), dev(r["y_prev"]), dev(r["y"]), dev(r["omega"]), 0.5)
+        np.testing.assert_allclose(float(w), float(r["omega_new"]), rtol=3e-6)
+
+
+@pytest.mark.parametrize("name", ["mixed_27x32", "mixed_400x300"])
+@pytest.mark.parametrize("iters", [10, 100])
+def test_power_iteration(golden, name, iters):
+    g = golden("power_iter.npz")
+    a, K, o, eng = golden_lp(g, name)
+    r = g.group(f"{name}/it{iters}")
+    s = eng.power_iteration(dev(r["b0"]), iters)
+    np.testing.assert_allclose(s, float(r["sigma"]), rtol=5e-5)
+    np.testing.assert_allclose(float(tp.spectral_norm_estimate_torch(K, iters, b0=dev(r["b0"]))), float(r["sigma"]), rtol=5e-5)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Ruiz
+# ---------------------------------------------------------------------------------------------------
+def test_ruiz_vs_golden(golden):
+    g = golden("ruiz.npz")
+    cases = sorted({"/".join(k.split("/")[:3]) for k in g.z.files})
+    assert len(cases) >= 8
+    for case in cases:
+        r = g.group(case)
+        iters = int(case.rsplit("it", 1)[1])
+        Ks, c_s, q_s, l_s, u_s, (D_col, D_row, *_), _ = tp.ruiz_precondition(dev(r["c"]), dev(r["K"]), dev(r["q"]), dev(r["l"]),
+                                                                             dev(r["u"]), device=DEV, max_iter=iters)
+        close(D_col, r["D_col"], 1e-5)
+        close(D_row, r["D_row"], 1e-5)
+        np.testing.assert_allclose(Ks.to_dense().cpu().numpy(), r["K_s"], rtol=1e-5, atol=1e-7)
+        # the transposed copy carries exactly the same scaled values
+        Kt = tp.CsrPair(Ks.n, Ks.m, Ks.t_rowptr, Ks.t_colidx, Ks.t_val)
+        assert torch.equal(Kt.to_dense().T.contiguous(), Ks.to_dense())
+        for got, key in ((c_s, "c_s"), (q_s, "q_s"), (l_s, "l_s"), (u_s, "u_s")):
+            np.testing.assert_allclose(got.cpu().numpy().reshape(-1), r[key], rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------
+# whole solves
+# ---------------------------------------------------------------------------------------------------
+SOLVE_RUNS = [(n, f"{a}_{p}") for n in ("mixed_27x32", "mixed_400x300", "box_200x150", "mixed_300x400_alleq")
+              for a in ("fixed", "adaptive") for p in ("nopw", "pw")]
+
+
+@pytest.mark.parametrize("name,mode", SOLVE_RUNS)
+def test_solve_vs_reference_trace(golden, name, mode):
+    g = golden("solve_trace.npz")
+    a, K, o, eng = golden_lp(g, name)
+    r = g.group(f"{name}/{mode}")
+    adaptive, pw = mode.startswith("adaptive"), mode.endswith("_pw")
+    trace = dict(kkt=[], omega=[], restarts=[])
+    x, obj, k, n, j, status, total = tp.pdlp_algorithm(K, int(a["m_ineq"]), dev(a["c"]), dev(a["q"]), dev(a["l"]), dev(a["u"]), DEV,
+                                                       tol=1e-4, verbose=False, primal_update=pw, adaptive=adaptive,
+                                                       b0=dev(r["b0"]), trace=trace)
+    assert status == "Solved" == str(r["status"])
+    assert x.shape == (int(a["n"]), 1)
+    checks = len(trace["kkt"]) - n
+    assert j == k + checks + 2 * n and checks % 3 == 0          # the reference's KKT-pass bookkeeping
+    if adaptive:
+        nfirst, nk, rt = 1, 4, 5e-2
+    else:
+        nfirst, nk, rt = min(len(trace["restarts"]), len(r["restarts"]), 5), 10, 5e-4
+    assert [tuple(v) for v in trace["restarts"][:nfirst]] == [tuple(int(t) for t in v) for v in r["restarts"][:nfirst]]
+    np.testing.assert_allclose(trace["kkt"][:nk], r["kkt_trace"][:nk], rtol=rt)
+    assert abs(obj - float(r["obj"])) <= 2e-3 * (1 + abs(float(r["obj"])))
+    if not np.isnan(r["opt_obj"]):
+        assert abs(obj - float(r["opt_obj"])) <= 2e-3 * (1 + abs(float(r["opt_obj"])))
+    assert abs(k - int(r["k"])) <= 0.5 * int(r["k"]) + 80
+    # the returned primal point is feasible to the solver's tolerance when re-checked on the host
+    xs = x.cpu().numpy().reshape(-1).astype(np.float64)
+    Kx = o.scipy().astype(np.float64) @ xs - o.q
+    viol = np.concatenate([np.minimum(Kx[:o.m_ineq], 0), Kx[o.m_ineq:]])
+    assert np.linalg.norm(viol) <= 1.5e-4 * (1 + np.linalg.norm(o.q))
+    assert np.all(xs >= o.l - 1e-5) and np.all(xs <= o.u + 1e-5)
+
+
+@pytest.mark.parametrize("mode", ["fixed", "adaptive"])
+def test_solve_tiny_known_answer(golden, mode):
+    g = golden("solve_trace.npz")
+    a, r = g.group("tiny"), g.group(f"tiny/{mode}")
+    x, obj, k, n, j, status, _ = tp.pdlp_algorithm(dev(a["K"]), int(a["m_ineq"]), dev(a["c"]), dev(a["q"]), dev(a["l"]), dev(a["u"]), DEV,
+                                                   verbose=False, adaptive=(mode == "adaptive"), b0=dev(r["b0"]))
+    assert (k, n, j, status) == (40, 1, 45, "Solved")
+    close(x, r["x"], 1e-4)
+    np.testing.assert_allclose(obj, float(r["obj"]), rtol=1e-4)
+
+
+def test_max_kkt_cap_and_statuses(golden):
+    g = golden("solve_trace.npz")
+    a, K, o, eng = golden_lp(g, "mixed_400x300")
+    r = g.group("mixed_400x300/fixed_nopw")
+    args = (K, int(a["m_ineq"]), dev(a["c"]), dev(a["q"]), dev(a["l"]), dev(a["u"]), DEV)
+    x, obj, k, n, j, status, _ = tp.pdlp_algorithm(*args, max_kkt=100, verbose=False, b0=dev(r["b0"]))
+    assert status == "Unsolved (KKT passes limit exceeded)" and j >= 100 and k <= 100
+    x, obj, k, n, j, status, _ = tp.pdlp_algorithm(*args, time_limit=0, verbose=False, b0=dev(r["b0"]))
+    assert status == "Unsolved (Time limit exceeded)" and k == 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# float64 mode and size-independent properties at a larger size
+# ---------------------------------------------------------------------------------------------------
+def test_float64_step_matches_oracle(golden):
+    g = golden("step_fixed.npz")
+    a, K, o, eng = golden_lp(g, "mixed_400x300", dtype=torch.float64)
+    eng.set_iterate(dev(a["x0"], torch.float64), dev(a["y0"], torch.float64))
+    eng.set_step(float(a["eta"]), float(a["omega"]), 1.0, 0)
+    eng.iterate(40, False)
+    xo, yo = a["x0"].astype(np.float64), a["y0"].astype(np.float64)
+    for _ in range(40):
+        xo, yo = o.step_fixed(xo, yo, float(a["eta"]), float(a["omega"]), 1.0)
+    x, y = eng.get_iterate(N.CUR)
+    close(x, xo, 1e-12)
+    close(y, yo, 1e-12)
+    out = eng.kkt(N.CUR, 0.7)
+    ref = o.kkt(xo, yo, 0.7)
+    for key in ("pr", "dr", "gap", "p", "d_adj", "kkt"):
+        np.testing.assert_allclose(out[key], float(ref[key]), rtol=1e-10, atol=1e-10)
+
+
+def test_large_instance_properties():
+    """200k x 200k, 5 nnz/row (too big for the dense reference): linearity of the products, the
+    <Kx,y> = <x,K'y> identity between the two CSR copies, and a step checked against the oracle."""
+    lp = gen_lp(200_000, 200_000, 5, seed=1, device=DEV)
+    K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
+    eng = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x1, x2 = torch.randn(lp.n, device=DEV, generator=g), torch.randn(lp.n, device=DEV, generator=g)
+    y1 = torch.randn(lp.m, device=DEV, generator=g)
+    lin = eng.spmv(2.0 * x1 + x2, False) - (2.0 * eng.spmv(x1, False) + eng.spmv(x2, False))
+    assert float(lin.abs().max()) <= 1e-4 * float(eng.spmv(x1, False).abs().max())
+    lhs = float((eng.spmv(x1, False).double() * y1.double()).sum())
+    rhs = float((x1.double() * eng.spmv(y1, True).double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * (abs(lhs) + abs(rhs) + 1.0)
+    o = orc.OracleLP(lp.m, lp.n, lp.m_ineq, *(t.cpu().numpy() for t in (lp.rowptr, lp.colidx, lp.val, lp.c, lp.q, lp.l, lp.u)))
+    x0 = torch.minimum(torch.maximum(x1, lp.l), lp.u)
+    y0 = y1.clone()
+    y0[:lp.m_ineq].clamp_(min=0)
+    eng.set_iterate(x0, y0)
+    eng.set_step(0.05, 1.3, 1.0, 0)
+    eng.iterate(3, True)
+    xo, yo, eta = x0.cpu().numpy(), y0.cpu().numpy(), np.float32(0.05)
+    for k in range(1, 4):
+        xo, yo, w, eta, _ = o.step_adaptive(xo, yo, eta, 1.3, 1.0, k)
+    x, y = eng.get_iterate(N.CUR)
+    close(x, xo, 2e-5)
+    close(y, yo, 2e-5)
+    np.testing.assert_allclose(eng.scalars()["eta"], float(eta), rtol=1e-4)
+    out, ref = eng.kkt(N.CUR, 1.3), o.kkt(xo, yo, 1.3)
+    for key in ("pr", "dr", "p", "d_adj", "kkt"):
+        np.testing.assert_allclose(out[key], float(ref[key]), rtol=1e-4)

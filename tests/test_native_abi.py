@@ -1,0 +1,61 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/pdlp_hip.h declares, and the ctypes mirror of pdlp_problem matches the header."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from torchpdlp_amd import _native as N
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "pdlp_hip.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pdlp_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_a_c_abi():
+    src = open(HEADER).read()
+    assert 'extern "C"' in src
+    assert "torch" not in re.sub(r"/\*.*?\*/", "", src, flags=re.S).lower()   # plain pointers and sizes only
+    assert len(declared_functions()) >= 30
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(N.LIB_PATH), "build the HIP library first: torchpdlp_amd/csrc/build.sh"
+    lib = C.CDLL(N.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(lib, name), f"{name} is declared in pdlp_hip.h but not exported"
+
+
+def test_binding_covers_the_header():
+    assert sorted(N.SIGNATURES) == declared_functions()
+    lib = N.load()
+    assert lib.pdlp_abi_version() == N.ABI_VERSION
+    assert lib.pdlp_strerror(0) == b"ok"
+    assert b"workspace" in lib.pdlp_strerror(-2)
+
+
+def test_problem_struct_matches_header():
+    src = open(HEADER).read()
+    body = re.search(r"typedef struct pdlp_problem \{(.*?)\} pdlp_problem;", src, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            names += [d.strip().split()[-1].lstrip("*") for d in decl.split(",")]
+    assert names == [f[0] for f in N.PdlpProblem._fields_]
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu():
+    lib = N.load()
+    assert lib.pdlp_primal_half(None, 0) == -1
+    assert lib.pdlp_kkt_local(None, 0, 0) == -1
+    assert lib.pdlp_vec_muldiv(7, 1, None, None, 0, None) == -1      # bad dtype code
+    with pytest.raises(N.PdlpError):
+        N.check(-1, "demo")

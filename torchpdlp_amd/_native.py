@@ -1,0 +1,101 @@
+"""ctypes binding of ``libpdlp_hip.so`` (C ABI: ``include/pdlp_hip.h``).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, an exception is
+raised.  Build it with ``torchpdlp_amd/csrc/build.sh`` (or ``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpdlp_hip.so")
+
+ABI_VERSION = 1
+PDLP_F32, PDLP_F64 = 0, 1
+CUR, AVG, PREV = 0, 1, 2
+(BUF_X_CUR, BUF_X_PREV, BUF_XBAR, BUF_X_AVG, BUF_Y_CUR, BUF_Y_PREV, BUF_Y_AVG, BUF_RED, BUF_X_SUM, BUF_Y_SUM,
+ BUF_SCALARS) = range(11)
+NRED, NSCAL = 8, 16
+# indices into the scalar block
+S_ETA, S_OMEGA, S_THETA, S_TAU, S_SIGMA, S_WPEND, S_ETASUM, S_K, S_INV1PT, S_ACCEPT, S_ETABAR, S_DEN = range(12)
+
+
+class PdlpProblem(C.Structure):
+    """mirror of ``struct pdlp_problem``"""
+    _fields_ = [("dtype", C.c_int32), ("device", C.c_int32), ("m", C.c_int64), ("n", C.c_int64), ("m_ineq", C.c_int64),
+                ("row0", C.c_int64), ("row1", C.c_int64), ("col0", C.c_int64), ("col1", C.c_int64),
+                ("K_rowptr", C.c_void_p), ("K_colidx", C.c_void_p), ("K_val", C.c_void_p),
+                ("KT_rowptr", C.c_void_p), ("KT_colidx", C.c_void_p), ("KT_val", C.c_void_p),
+                ("c", C.c_void_p), ("l", C.c_void_p), ("u", C.c_void_p), ("q", C.c_void_p),
+                ("d_col", C.c_void_p), ("d_row", C.c_void_p), ("stream", C.c_void_p)]
+
+
+# every symbol include/pdlp_hip.h declares: name -> (restype, argtypes)
+_H = C.c_void_p
+_I, _I64, _D, _P = C.c_int, C.c_int64, C.c_double, C.c_void_p
+SIGNATURES = {
+    "pdlp_strerror": (C.c_char_p, [_I]),
+    "pdlp_abi_version": (_I, []),
+    "pdlp_workspace_bytes": (_I, [C.POINTER(PdlpProblem), C.POINTER(_I64)]),
+    "pdlp_create": (_I, [C.POINTER(_H), C.POINTER(PdlpProblem), _P, _I64]),
+    "pdlp_destroy": (None, [_H]),
+    "pdlp_buffer_ptr": (_I, [_H, _I, C.POINTER(_P)]),
+    "pdlp_set_iterate": (_I, [_H, _P, _P]),
+    "pdlp_get_iterate": (_I, [_H, _I, _P, _P]),
+    "pdlp_set_step": (_I, [_H, _D, _D, _D, _I64]),
+    "pdlp_set_omega": (_I, [_H, _D]),
+    "pdlp_get_scalars": (_I, [_H, C.POINTER(_D)]),
+    "pdlp_primal_half": (_I, [_H, _I]),
+    "pdlp_dual_half": (_I, [_H, _I]),
+    "pdlp_adaptive_reduce": (_I, [_H]),
+    "pdlp_adaptive_update": (_I, [_H]),
+    "pdlp_iterate": (_I, [_H, _I, _I]),
+    "pdlp_fixed_advance": (_I, [_H, _I]),
+    "pdlp_flush_average": (_I, [_H]),
+    "pdlp_compute_average": (_I, [_H]),
+    "pdlp_kkt_local": (_I, [_H, _I, _I]),
+    "pdlp_kkt_finish": (_I, [_H, _D, C.POINTER(_D)]),
+    "pdlp_restart": (_I, [_H, _I]),
+    "pdlp_restart_distance_local": (_I, [_H]),
+    "pdlp_mark_restart_point": (_I, [_H]),
+    "pdlp_read_red": (_I, [_H, C.POINTER(_D)]),
+    "pdlp_spmv": (_I, [_H, _I, _P, _P]),
+    "pdlp_power_iteration": (_I, [_H, _P, _I, _P, _P, C.POINTER(_D)]),
+    "pdlp_csr_row_scale_factors": (_I, [_I, _I64, _P, _P, _D, _P, _P]),
+    "pdlp_csr_div_rows": (_I, [_I, _I64, _P, _P, _P, _P]),
+    "pdlp_csr_div_cols": (_I, [_I, _I64, _P, _P, _P, _P, _P]),
+    "pdlp_vec_muldiv": (_I, [_I, _I64, _P, _P, _I, _P]),
+    "pdlp_vec_max_dev_from_one": (_I, [_I, _I64, _P, _P, C.POINTER(_D), _P]),
+}
+
+_lib = None
+
+
+class PdlpError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (no GPU needed to load it; calls need one)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PdlpError(f"{LIB_PATH} not found: the HIP extension is not built "
+                        f"(run torchpdlp_amd/csrc/build.sh). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pdlp_abi_version() != ABI_VERSION:
+        raise PdlpError(f"libpdlp_hip.so ABI {lib.pdlp_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().pdlp_strerror(rc).decode()
+        raise PdlpError(f"{what or 'libpdlp_hip'} failed: {msg} (code {rc})")

@@ -1,0 +1,1139 @@
+// pdlp_hip.hip -- restarted PDHG for LP on AMD Instinct MI355X (gfx950, wave64), C ABI in include/pdlp_hip.h.
+//
+// Design (DESIGN.md has the long form):
+//   * K is stored twice (CSR of K, CSR of K'); both products are row-parallel SpMVs, no atomics.
+//   * One kernel per half-iteration: a CSR "stream" SpMV whose epilogue does the projection, the
+//     extrapolation / dual ascent, the eta-weighted running sums and the step-size-rule partial sums.
+//     Row blocks (<= 256 rows, <= 2048 non-zeros, built once on the host) are processed by 256-thread
+//     workgroups: the block's non-zeros are read fully coalesced, multiplied with the gathered vector
+//     entries and staged in LDS, then 1..64 lanes per row reduce their segment (wave shuffles), and the
+//     lane holding the row sum runs the epilogue.  Rows longer than 2048 get a whole workgroup.
+//   * The launch is a fixed grid of <= 2048 workgroups striding over the row blocks, so the norm
+//     partial sums are 2048 x 4 doubles and their final reduction is deterministic.
+//   * All step-size state (eta, omega, tau, sigma, pending average weight, iteration count) lives in
+//     device memory, so a whole restart period runs without a host synchronisation.
+// This bandwidth-bound path uses no MFMA.  Written for gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "pdlp_hip.h"
+
+namespace {
+
+constexpr int BLOCK = 256;       // threads per workgroup (4 wave64)
+constexpr int NNZ_CAP = 2048;    // non-zeros staged in LDS per row block
+constexpr int ROWS_CAP = 256;    // rows per row block (one epilogue lane each at most)
+constexpr int MAX_GRID = 2048;   // 256 CUs x 8 workgroups
+constexpr int NACC = 4;          // partial sums a kernel may produce
+
+// indices into the device scalar block (double[PDLP_NSCAL])
+enum { S_ETA = 0, S_OMEGA, S_THETA, S_TAU, S_SIGMA, S_WPEND, S_ETASUM, S_K, S_INV1PT, S_ACCEPT, S_ETABAR, S_DEN };
+
+#define HIP_TRY(expr)                                                   \
+    do {                                                                \
+        hipError_t e_ = (expr);                                         \
+        if (e_ != hipSuccess) return PDLP_ERR_HIP_BASE - (int)e_;       \
+    } while (0)
+
+template <typename T> __device__ __forceinline__ T shfl_xor_t(T v, int m) { return __shfl_xor(v, m, 64); }
+
+// sum of `v` over the 256-thread workgroup, valid in thread 0.  `buf` holds >= 4 entries.
+template <typename T> __device__ __forceinline__ T block_sum(T v, T* buf)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += shfl_xor_t(v, off);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) buf[w] = v;
+    __syncthreads();
+    return buf[0] + buf[1] + buf[2] + buf[3];
+}
+
+// ------------------------------------------------------------------------------------------------
+// epilogues: called once per row with the row's dot product
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct StoreEpi {
+    static constexpr int NA = 0;
+    T* out;
+    __device__ void load() {}
+    __device__ void operator()(int i, T s, double*) const { out[i] = s; }
+};
+
+// primal half-step over this rank's rows of K' (= its variables).  kty = (K'y)_j.
+// step.py:25-30 (fixed) / :74-82 (adaptive); running sum pdhg.py:107.
+template <typename T, bool ADAPT> struct PrimalEpi {
+    static constexpr int NA = ADAPT ? 1 : 0;
+    const T* x_old; T* x_new; T* xbar; const T* c; const T* l; const T* u; T* x_sum; const double* sc;
+    T tau = 0, theta = 0, w = 0;
+    __device__ void load()
+    {
+        tau = (T)sc[S_TAU];
+        theta = (T)sc[S_THETA];
+        w = ADAPT ? (T)sc[S_WPEND] : (T)sc[S_ETA];
+    }
+    __device__ void operator()(int j, T kty, double* acc) const
+    {
+        const T xo = x_old[j];
+        const T grad = c[j] - kty;
+        T v = xo - tau * grad;
+        const T lo = l[j], hi = u[j];
+        v = v < lo ? lo : v;
+        v = v > hi ? hi : v;
+        const T d = v - xo;
+        x_new[j] = v;
+        xbar[j] = v + theta * d;
+        if (ADAPT) {
+            x_sum[j] += w * xo;           // weight of the PREVIOUS iterate, known only now
+            acc[0] += (double)d * (double)d;
+        } else {
+            x_sum[j] += w * v;
+        }
+    }
+};
+
+// dual half-step over this rank's rows of K (= its constraints).  kxbar = (K xbar)_i.
+// step.py:33-38 / :85-96; running sum pdhg.py:108.
+template <typename T, bool ADAPT> struct DualEpi {
+    static constexpr int NA = ADAPT ? 2 : 0;
+    const T* y_old; T* y_new; const T* q; T* y_sum; T* kx; const double* sc; int ineq_end;
+    T sigma = 0, w = 0, inv1pt = 0;
+    __device__ void load()
+    {
+        sigma = (T)sc[S_SIGMA];
+        w = ADAPT ? (T)sc[S_WPEND] : (T)sc[S_ETA];
+        inv1pt = (T)sc[S_INV1PT];
+    }
+    __device__ void operator()(int i, T kxbar, double* acc) const
+    {
+        const T yo = y_old[i];
+        T v = yo + sigma * (q[i] - kxbar);
+        if (i < ineq_end && v < (T)0) v = (T)0;
+        y_new[i] = v;
+        if (ADAPT) {
+            y_sum[i] += w * yo;
+            const T dy = v - yo;
+            // K dx = (K xbar - K x) / (1 + theta) because xbar = x + (1 + theta) dx; kx caches K x
+            const T kxo = kx[i];
+            const T kdx = (kxbar - kxo) * inv1pt;
+            kx[i] = kxo + kdx;
+            acc[0] += (double)dy * (double)dy;
+            acc[1] += (double)dy * (double)kdx;
+        } else {
+            y_sum[i] += w * v;
+        }
+    }
+};
+
+// KKT, dual side (helpers.py:75-84,94 with project_lambda_box helpers.py:21-37 and pdhg.py:11-17)
+template <typename T, bool UNSCALE> struct KktDualEpi {
+    static constexpr int NA = 4;
+    const T* x; const T* c; const T* l; const T* u; const T* dcol;
+    __device__ void load() {}
+    __device__ void operator()(int j, T kty, double* acc) const
+    {
+        T cj = c[j], lo = l[j], hi = u[j], xj = x[j];
+        T g = cj - kty;
+        if (UNSCALE) {            // K_u'(D_row y) = (K_s'y)/D_col, c_u = c_s/D_col, l_u = l_s D_col, x_u = D_col x
+            const T d = dcol[j];
+            g = g / d; cj = cj / d; lo = lo * d; hi = hi * d; xj = xj * d;
+        }
+        const bool ninf = isinf(lo) && lo < (T)0, pinf = isinf(hi) && hi > (T)0;
+        T lam;
+        if (ninf && pinf) lam = (T)0;
+        else if (ninf) lam = g < (T)0 ? g : (T)0;
+        else if (pinf) lam = g > (T)0 ? g : (T)0;
+        else lam = g;
+        const T ld = ninf ? (T)0 : lo, ud = pinf ? (T)0 : hi;
+        const T r = g - lam;
+        acc[0] += (double)r * (double)r;
+        acc[1] += (double)ld * (double)(lam > (T)0 ? lam : (T)0);
+        acc[2] += (double)ud * (double)(lam < (T)0 ? lam : (T)0);
+        acc[3] += (double)cj * (double)xj;
+    }
+};
+
+// KKT, primal side (helpers.py:77,87-91).  Optionally keeps K x for the adaptive step's cache.
+template <typename T, bool UNSCALE> struct KktPrimalEpi {
+    static constexpr int NA = 2;
+    const T* y; const T* q; const T* drow; T* kx_out; int ineq_end;
+    __device__ void load() {}
+    __device__ void operator()(int i, T kx, double* acc) const
+    {
+        if (kx_out) kx_out[i] = kx;
+        T qi = q[i], yi = y[i];
+        T r = kx - qi;
+        if (UNSCALE) {            // K_u (D_col x) = (K_s x)/D_row, q_u = q_s/D_row, y_u = D_row y
+            const T d = drow[i];
+            r = r / d; qi = qi / d; yi = yi * d;
+        }
+        if (i < ineq_end && r > (T)0) r = (T)0;
+        acc[0] += (double)r * (double)r;
+        acc[1] += (double)qi * (double)yi;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// the fused CSR kernel
+// ------------------------------------------------------------------------------------------------
+template <typename T, class Epi>
+__global__ __launch_bounds__(BLOCK) void k_csr_fused(const int32_t* __restrict__ blk, int nblk,
+                                                     const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                                                     const T* __restrict__ va, const T* __restrict__ vin, Epi epi,
+                                                     double* __restrict__ partials)
+{
+    __shared__ T prod[NNZ_CAP];
+    __shared__ T tred[4];
+    __shared__ double dred[4];
+    const int tid = threadIdx.x;
+    epi.load();
+    double acc[NACC] = {0.0, 0.0, 0.0, 0.0};
+
+    for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
+        const int r0 = blk[b], r1 = blk[b + 1];
+        const int a = rp[r0], e = rp[r1];
+        const int nn = e - a, nrows = r1 - r0;
+        if (nn <= NNZ_CAP) {
+            // stage the products: coalesced value/index reads, gathered vector reads
+            for (int i = tid; i < nn; i += BLOCK) prod[i] = va[a + i] * vin[ci[a + i]];
+            __syncthreads();
+            // 1..64 lanes per row (a power of two, so a row never straddles a wave)
+            int tpr = 1 << (31 - __clz(BLOCK / nrows));
+            tpr = tpr > 64 ? 64 : tpr;
+            const int lr = tid / tpr, lt = tid & (tpr - 1);
+            T s = (T)0;
+            int row = r0 + lr;
+            if (lr < nrows) {
+                const int p0 = rp[row] - a, p1 = rp[row + 1] - a;
+                for (int p = p0 + lt; p < p1; p += tpr) s += prod[p];
+            }
+            for (int off = tpr >> 1; off > 0; off >>= 1) s += shfl_xor_t(s, off);
+            if (lr < nrows && lt == 0) epi(row, s, acc);
+            __syncthreads();
+        } else {
+            // one long row: the whole workgroup strides over it
+            T s = (T)0;
+            for (int i = a + tid; i < e; i += BLOCK) s += va[i] * vin[ci[i]];
+            s = block_sum(s, tred);
+            if (tid == 0) epi(r0, s, acc);
+            __syncthreads();
+        }
+    }
+    if (Epi::NA > 0) {
+#pragma unroll
+        for (int r = 0; r < Epi::NA; ++r) {
+            const double v = block_sum(acc[r], dred);
+            if (tid == 0) partials[(size_t)blockIdx.x * NACC + r] = v;
+        }
+    }
+}
+
+// red[off + r] = sum over blocks of partials[b][r]   (one workgroup; fixed order => deterministic)
+__global__ __launch_bounds__(BLOCK) void k_finalize(const double* __restrict__ partials, int nblocks, int na,
+                                                    double* __restrict__ red, int off)
+{
+    __shared__ double dred[4];
+    for (int r = 0; r < na; ++r) {
+        double s = 0.0;
+        for (int b = threadIdx.x; b < nblocks; b += BLOCK) s += partials[(size_t)b * NACC + r];
+        s = block_sum(s, dred);
+        if (threadIdx.x == 0) red[off + r] = s;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scalar kernels (one thread): the reference keeps eta/omega as 0-dim tensors of the working dtype
+// ------------------------------------------------------------------------------------------------
+template <typename T> __global__ void k_set_step(double* sc, double eta, double omega, double theta, double k)
+{
+    const T e = (T)eta, w = (T)omega, th = (T)theta;
+    sc[S_ETA] = (double)e;
+    sc[S_OMEGA] = (double)w;
+    sc[S_THETA] = (double)th;
+    sc[S_TAU] = (double)(T)(e / w);             // step.py:27 / :74
+    sc[S_SIGMA] = (double)(T)(e * w);           // step.py:34 / :75
+    sc[S_INV1PT] = (double)(T)((T)1 / ((T)1 + th));
+    sc[S_K] = k;
+}
+
+// omega <- new primal weight (enhancements.py:77); tau, sigma follow from the eta currently on the device
+template <typename T> __global__ void k_set_omega(double* sc, double omega)
+{
+    const T e = (T)sc[S_ETA], w = (T)omega;
+    sc[S_OMEGA] = (double)w;
+    sc[S_TAU] = (double)(T)(e / w);
+    sc[S_SIGMA] = (double)(T)(e * w);
+}
+
+__global__ void k_reset_average(double* sc)
+{
+    sc[S_WPEND] = 0.0;
+    sc[S_ETASUM] = 0.0;
+}
+
+// fixed step: eta_total += eta, k += 1, `iters` times (pdhg.py:76,109) in the working precision
+template <typename T> __global__ void k_fixed_advance(double* sc, int iters)
+{
+    T s = (T)sc[S_ETASUM];
+    const T e = (T)sc[S_ETA];
+    for (int i = 0; i < iters; ++i) s = s + e;
+    sc[S_ETASUM] = (double)s;
+    sc[S_K] += (double)iters;
+}
+
+// adaptive rule, step.py:91-115 with quirk Q1 (one trial; a rejected step is kept), then
+// pdhg.py:107-112: weight of the new iterate, eta_total, eta <- eta_hat.
+template <typename T> __device__ void adaptive_rule(double* sc, const double* red)
+{
+    const T eta = (T)sc[S_ETA], omega = (T)sc[S_OMEGA];
+    const double k1 = sc[S_K] + 1.0;                       // the reference's 1-based k of this step
+    const T den = (T)2 * (T)red[2];                        // step.py:96
+    T eta_bar, t1;
+    if (den != (T)0) {                                     // step.py:99-102
+        const T nx = (T)sqrt(red[0]), ny = (T)sqrt(red[1]);
+        const T num = omega * (nx * nx) + (ny * ny) / omega;
+        eta_bar = num / (T)fabs((double)den);
+        t1 = (T)(1.0 - pow(k1 + 1.0, -0.3)) * eta_bar;
+    } else {                                               // step.py:104-105
+        eta_bar = (T)INFINITY;
+        t1 = (T)INFINITY;
+    }
+    const T t2 = (T)(1.0 + pow(k1 + 1.0, -0.6)) * eta;     // step.py:107
+    const T eta_p = t1 < t2 ? t1 : t2;                     // step.py:108
+    const bool accept = eta <= eta_bar;                    // step.py:110
+    const T w = accept ? eta : eta_p;                      // first returned value (:111 / :115)
+    sc[S_WPEND] = (double)w;
+    sc[S_ETASUM] = (double)(T)((T)sc[S_ETASUM] + w);       // pdhg.py:109
+    sc[S_ETA] = (double)eta_p;                             // pdhg.py:112
+    sc[S_TAU] = (double)(T)(eta_p / omega);
+    sc[S_SIGMA] = (double)(T)(eta_p * omega);
+    sc[S_K] = k1;
+    sc[S_ACCEPT] = accept ? 1.0 : 0.0;
+    sc[S_ETABAR] = (double)eta_bar;
+    sc[S_DEN] = (double)den;
+}
+
+template <typename T> __global__ void k_adaptive_update(double* sc, const double* red) { adaptive_rule<T>(sc, red); }
+
+// single-rank fusion of pdlp_adaptive_reduce + pdlp_adaptive_update
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_adaptive_reduce_update(const double* __restrict__ pa, int na_blocks,
+                                                                  const double* __restrict__ pb, int nb_blocks,
+                                                                  double* __restrict__ red, double* __restrict__ sc, int update)
+{
+    __shared__ double dred[4];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int b = threadIdx.x; b < na_blocks; b += BLOCK) s0 += pa[(size_t)b * NACC];
+    for (int b = threadIdx.x; b < nb_blocks; b += BLOCK) {
+        s1 += pb[(size_t)b * NACC];
+        s2 += pb[(size_t)b * NACC + 1];
+    }
+    s0 = block_sum(s0, dred);
+    s1 = block_sum(s1, dred);
+    s2 = block_sum(s2, dred);
+    if (threadIdx.x == 0) {
+        red[0] = s0; red[1] = s1; red[2] = s2;
+        if (update) adaptive_rule<T>(sc, red);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// vector kernels
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_flush(int64_t n, T* __restrict__ sum, const T* __restrict__ v, const double* sc)
+{
+    const T w = (T)sc[S_WPEND];
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) sum[i] += w * v[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_average(int64_t n, T* __restrict__ avg, const T* __restrict__ sum, const double* sc)
+{
+    const T s = (T)sc[S_ETASUM];
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) avg[i] = sum[i] / s;
+}
+
+__global__ void k_clear_pending(double* sc) { sc[S_WPEND] = 0.0; }
+
+// partials[b][0] = sum (a-b)^2 (b may be null: sum a^2)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_sqdiff(int64_t n, const T* __restrict__ a, const T* __restrict__ b,
+                                                  double* __restrict__ partials)
+{
+    __shared__ double dred[4];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const T d = b ? a[i] - b[i] : a[i];
+        s += (double)d * (double)d;
+    }
+    s = block_sum(s, dred);
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * NACC] = s;
+}
+
+// v /= sqrt(red[idx])  (power iteration normalisation, helpers.py:50)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_div_by_norm(int64_t n, T* __restrict__ v, const double* __restrict__ red, int idx)
+{
+    const T nb = (T)sqrt(red[idx]);
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) v[i] = v[i] / nb;
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_muldiv(int64_t n, T* __restrict__ a, const T* __restrict__ b, int op)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK)
+        a[i] = op ? a[i] / b[i] : a[i] * b[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_max_dev_from_one(int64_t n, const T* __restrict__ v, double* __restrict__ out)
+{
+    __shared__ double dred[4];
+    double mx = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const T d = (T)fabs((double)((T)1 - v[i]));
+        mx = (double)d > mx ? (double)d : mx;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = shfl_xor_t(mx, off);
+        mx = o > mx ? o : mx;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) dred[w] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) mx = dred[k] > mx ? dred[k] : mx;
+        // non-negative doubles order like their bit patterns
+        atomicMax((unsigned long long*)out, (unsigned long long)__double_as_longlong(mx));
+    }
+}
+
+// ---- Ruiz building blocks: 8 lanes per row ------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_row_scale_factors(int64_t rows, const int32_t* __restrict__ rp,
+                                                             const T* __restrict__ va, T eps, T* __restrict__ norm)
+{
+    const int64_t g = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 3;
+    const int lt = threadIdx.x & 7;
+    const int64_t stride = ((int64_t)gridDim.x * BLOCK) >> 3;
+    for (int64_t i = g; i < ((rows + stride - 1) / stride) * stride; i += stride) {
+        T mx = (T)0;
+        if (i < rows)
+            for (int p = rp[i] + lt; p < rp[i + 1]; p += 8) {
+                const T a = (T)fabs((double)va[p]);
+                mx = a > mx ? a : mx;
+            }
+        for (int off = 4; off > 0; off >>= 1) {
+            const T o = shfl_xor_t(mx, off);
+            mx = o > mx ? o : mx;
+        }
+        if (i < rows && lt == 0) {
+            const T r = (T)sqrt((double)mx);          // enhancements.py:49 / :54
+            norm[i] = r < eps ? (T)1 : r;             // :50 / :55
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_div_rows(int64_t rows, const int32_t* __restrict__ rp, T* __restrict__ va,
+                                                    const T* __restrict__ norm)
+{
+    const int64_t g = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 3;
+    const int lt = threadIdx.x & 7;
+    const int64_t stride = ((int64_t)gridDim.x * BLOCK) >> 3;
+    for (int64_t i = g; i < rows; i += stride) {
+        const T r = norm[i];
+        for (int p = rp[i] + lt; p < rp[i + 1]; p += 8) va[p] = va[p] / r;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_div_cols(int64_t nnz, const int32_t* __restrict__ ci, T* __restrict__ va,
+                                                    const T* __restrict__ norm)
+{
+    for (int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x; p < nnz; p += (int64_t)gridDim.x * BLOCK)
+        va[p] = va[p] / norm[ci[p]];
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct Schedule {
+    int32_t* blk = nullptr;   // device, nblk+1 row starts
+    int nblk = 0;
+    int grid = 0;
+};
+
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+inline int grid_for(int64_t n) { int64_t g = (n + BLOCK - 1) / BLOCK; return (int)(g < 1 ? 1 : (g > MAX_GRID ? MAX_GRID : g)); }
+
+// upper bound on the number of row blocks: two consecutive blocks together exceed a cap
+inline int64_t max_blocks(int64_t rows, int64_t nnz) { return 2 * (rows / ROWS_CAP + nnz / NNZ_CAP) + 4; }
+
+void build_schedule_host(const std::vector<int32_t>& rp, int64_t rows, std::vector<int32_t>& out)
+{
+    out.clear();
+    int64_t r = 0;
+    out.push_back(0);
+    while (r < rows) {
+        int64_t e = r;
+        int64_t nnz = 0;
+        while (e < rows && e - r < ROWS_CAP) {
+            const int64_t len = (int64_t)rp[e + 1] - rp[e];
+            if (nnz + len > NNZ_CAP) break;
+            nnz += len;
+            ++e;
+        }
+        if (e == r) e = r + 1;   // a single row longer than NNZ_CAP: whole-workgroup path
+        out.push_back((int32_t)e);
+        r = e;
+    }
+}
+
+}  // namespace
+
+struct pdlp_solver {
+    pdlp_problem p;
+    hipStream_t stream;
+    size_t es;                    // element size
+    int64_t nl, ml;               // local variable / constraint counts
+    int ineq_end;                 // local rows below this index are inequalities
+    Schedule sK, sKT;
+    char* xb[3];                  // full-length primal buffers; roles via ix_*
+    char* yb[3];
+    int ix_cur, ix_prev, ix_avg;  // (x and y rotate together)
+    char* xbar;
+    char *x_sum, *y_sum, *x_last, *y_last;
+    char* kxb[3];                 // K x caches: [0] running, [1] from KKT(cur), [2] from KKT(avg)
+    bool kx_valid, cand_valid[2];
+    double *partA, *partB, *red, *sc;
+    int last_gridA, last_gridB;   // grids of the last primal / dual launch (adaptive reduce)
+};
+
+namespace {
+
+template <typename T, class Epi>
+int launch_csr(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* partials)
+{
+    const Schedule& s = transpose ? h->sKT : h->sK;
+    if (s.nblk == 0) return PDLP_OK;
+    const int32_t* rp = transpose ? h->p.KT_rowptr : h->p.K_rowptr;
+    const int32_t* ci = transpose ? h->p.KT_colidx : h->p.K_colidx;
+    const T* va = (const T*)(transpose ? h->p.KT_val : h->p.K_val);
+    hipLaunchKernelGGL((k_csr_fused<T, Epi>), dim3(s.grid), dim3(BLOCK), 0, h->stream, s.blk, s.nblk, rp, ci, va,
+                       (const T*)vin, epi, partials);
+    HIP_TRY(hipGetLastError());
+    return PDLP_OK;
+}
+
+template <typename T> T* xloc(pdlp_handle h, int ix) { return (T*)h->xb[ix] + h->p.col0; }
+template <typename T> T* yloc(pdlp_handle h, int ix) { return (T*)h->yb[ix] + h->p.row0; }
+
+template <typename T> int primal_half_t(pdlp_handle h, int adaptive)
+{
+    const double* sc = h->sc;
+    if (adaptive) {
+        PrimalEpi<T, true> e{xloc<T>(h, h->ix_cur), xloc<T>(h, h->ix_prev), (T*)h->xbar + h->p.col0, (const T*)h->p.c,
+                             (const T*)h->p.l, (const T*)h->p.u, (T*)h->x_sum, sc};
+        h->last_gridA = h->sKT.grid;
+        return launch_csr<T>(h, true, h->yb[h->ix_cur], e, h->partA);
+    }
+    PrimalEpi<T, false> e{xloc<T>(h, h->ix_cur), xloc<T>(h, h->ix_prev), (T*)h->xbar + h->p.col0, (const T*)h->p.c,
+                          (const T*)h->p.l, (const T*)h->p.u, (T*)h->x_sum, sc};
+    return launch_csr<T>(h, true, h->yb[h->ix_cur], e, h->partA);
+}
+
+template <typename T> int refresh_kx_t(pdlp_handle h)
+{
+    StoreEpi<T> e{(T*)h->kxb[0]};
+    int rc = launch_csr<T>(h, false, h->xb[h->ix_cur], e, h->partB);
+    if (rc == PDLP_OK) h->kx_valid = true;
+    return rc;
+}
+
+template <typename T> int dual_half_t(pdlp_handle h, int adaptive)
+{
+    int rc;
+    if (adaptive) {
+        if (!h->kx_valid && (rc = refresh_kx_t<T>(h)) != PDLP_OK) return rc;
+        DualEpi<T, true> e{yloc<T>(h, h->ix_cur), yloc<T>(h, h->ix_prev), (const T*)h->p.q, (T*)h->y_sum, (T*)h->kxb[0],
+                           h->sc, h->ineq_end};
+        h->last_gridB = h->sK.grid;
+        rc = launch_csr<T>(h, false, h->xbar, e, h->partB);
+    } else {
+        DualEpi<T, false> e{yloc<T>(h, h->ix_cur), yloc<T>(h, h->ix_prev), (const T*)h->p.q, (T*)h->y_sum, (T*)h->kxb[0],
+                            h->sc, h->ineq_end};
+        rc = launch_csr<T>(h, false, h->xbar, e, h->partB);
+        h->kx_valid = false;
+    }
+    if (rc != PDLP_OK) return rc;
+    const int t = h->ix_cur;   // the freshly written buffers become current, the old ones previous
+    h->ix_cur = h->ix_prev;
+    h->ix_prev = t;
+    h->cand_valid[0] = h->cand_valid[1] = false;
+    return PDLP_OK;
+}
+
+template <typename T> int kkt_local_t(pdlp_handle h, int which, int unscaled)
+{
+    const int ix = which == PDLP_CUR ? h->ix_cur : (which == PDLP_AVG ? h->ix_avg : h->ix_prev);
+    T* kx_out = which == PDLP_CUR ? (T*)h->kxb[1] : (which == PDLP_AVG ? (T*)h->kxb[2] : nullptr);
+    int rc;
+    if (unscaled) {
+        KktDualEpi<T, true> ed{xloc<T>(h, ix), (const T*)h->p.c, (const T*)h->p.l, (const T*)h->p.u, (const T*)h->p.d_col};
+        if ((rc = launch_csr<T>(h, true, h->yb[ix], ed, h->partA)) != PDLP_OK) return rc;
+        KktPrimalEpi<T, true> ep{yloc<T>(h, ix), (const T*)h->p.q, (const T*)h->p.d_row, kx_out, h->ineq_end};
+        if ((rc = launch_csr<T>(h, false, h->xb[ix], ep, h->partB)) != PDLP_OK) return rc;
+    } else {
+        KktDualEpi<T, false> ed{xloc<T>(h, ix), (const T*)h->p.c, (const T*)h->p.l, (const T*)h->p.u, nullptr};
+        if ((rc = launch_csr<T>(h, true, h->yb[ix], ed, h->partA)) != PDLP_OK) return rc;
+        KktPrimalEpi<T, false> ep{yloc<T>(h, ix), (const T*)h->p.q, nullptr, kx_out, h->ineq_end};
+        if ((rc = launch_csr<T>(h, false, h->xb[ix], ep, h->partB)) != PDLP_OK) return rc;
+    }
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partA, h->sKT.nblk ? h->sKT.grid : 0, 4, h->red, 0);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partB, h->sK.nblk ? h->sK.grid : 0, 2, h->red, 4);
+    HIP_TRY(hipGetLastError());
+    if (which != PDLP_PREV) h->cand_valid[which == PDLP_CUR ? 0 : 1] = true;
+    return PDLP_OK;
+}
+
+template <typename T> void kkt_finish_t(const double* r, double omega_d, double* out)
+{
+    // helpers.py:84-94,102-106 in the working precision
+    const T p = (T)r[3], d = (T)r[5], lp = (T)r[1], un = (T)r[2];
+    const T adj = d + lp + un;
+    const T gap = adj - p;
+    const T pr = (T)std::sqrt(r[4]), dr = (T)std::sqrt(r[0]);
+    const T w = (T)omega_d, w2 = w * w;
+    const T kkt = (T)std::sqrt((double)(w2 * (pr * pr) + (dr * dr) / w2 + gap * gap));
+    out[0] = pr; out[1] = dr; out[2] = gap; out[3] = p; out[4] = adj; out[5] = kkt;
+}
+
+#define DISPATCH(h, fn, ...) ((h)->p.dtype == PDLP_F32 ? fn<float>(__VA_ARGS__) : fn<double>(__VA_ARGS__))
+
+template <typename T> int flush_t(pdlp_handle h)
+{
+    hipLaunchKernelGGL(k_flush<T>, dim3(grid_for(h->nl)), dim3(BLOCK), 0, h->stream, h->nl, (T*)h->x_sum,
+                       (const T*)xloc<T>(h, h->ix_cur), h->sc);
+    hipLaunchKernelGGL(k_flush<T>, dim3(grid_for(h->ml)), dim3(BLOCK), 0, h->stream, h->ml, (T*)h->y_sum,
+                       (const T*)yloc<T>(h, h->ix_cur), h->sc);
+    hipLaunchKernelGGL(k_clear_pending, dim3(1), dim3(1), 0, h->stream, h->sc);
+    HIP_TRY(hipGetLastError());
+    return PDLP_OK;
+}
+
+template <typename T> int average_t(pdlp_handle h)
+{
+    hipLaunchKernelGGL(k_average<T>, dim3(grid_for(h->nl)), dim3(BLOCK), 0, h->stream, h->nl, xloc<T>(h, h->ix_avg),
+                       (const T*)h->x_sum, h->sc);
+    hipLaunchKernelGGL(k_average<T>, dim3(grid_for(h->ml)), dim3(BLOCK), 0, h->stream, h->ml, yloc<T>(h, h->ix_avg),
+                       (const T*)h->y_sum, h->sc);
+    HIP_TRY(hipGetLastError());
+    return PDLP_OK;
+}
+
+template <typename T> int distance_t(pdlp_handle h)
+{
+    const int ga = grid_for(h->nl), gb = grid_for(h->ml);
+    hipLaunchKernelGGL(k_sqdiff<T>, dim3(ga), dim3(BLOCK), 0, h->stream, h->nl, (const T*)h->x_last,
+                       (const T*)xloc<T>(h, h->ix_cur), h->partA);
+    hipLaunchKernelGGL(k_sqdiff<T>, dim3(gb), dim3(BLOCK), 0, h->stream, h->ml, (const T*)h->y_last,
+                       (const T*)yloc<T>(h, h->ix_cur), h->partB);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partA, ga, 1, h->red, 0);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partB, gb, 1, h->red, 1);
+    HIP_TRY(hipGetLastError());
+    return PDLP_OK;
+}
+
+template <typename T> int spmv_t(pdlp_handle h, int transpose, const void* in_full, void* out_local)
+{
+    StoreEpi<T> e{(T*)out_local};
+    return launch_csr<T>(h, transpose != 0, in_full, e, h->partA);
+}
+
+template <typename T> int power_iteration_t(pdlp_handle h, const void* b0, int iters, void* work_n, void* work_m, double* sigma)
+{
+    T* b = (T*)work_n;
+    T* t = (T*)work_m;
+    int rc;
+    HIP_TRY(hipMemcpyAsync(b, b0, (size_t)h->p.n * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+    const int g = grid_for(h->p.n);
+    for (int it = 0; it < iters; ++it) {                                   // helpers.py:48-50
+        if ((rc = spmv_t<T>(h, 0, b, t)) != PDLP_OK) return rc;
+        if ((rc = spmv_t<T>(h, 1, t, b)) != PDLP_OK) return rc;
+        hipLaunchKernelGGL(k_sqdiff<T>, dim3(g), dim3(BLOCK), 0, h->stream, h->p.n, (const T*)b, (const T*)nullptr, h->partA);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partA, g, 1, h->red, 0);
+        hipLaunchKernelGGL(k_div_by_norm<T>, dim3(g), dim3(BLOCK), 0, h->stream, h->p.n, b, h->red, 0);
+    }
+    if ((rc = spmv_t<T>(h, 0, b, t)) != PDLP_OK) return rc;               // helpers.py:51
+    const int gm = grid_for(h->p.m);
+    hipLaunchKernelGGL(k_sqdiff<T>, dim3(gm), dim3(BLOCK), 0, h->stream, h->p.m, (const T*)t, (const T*)nullptr, h->partA);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partA, gm, 1, h->red, 0);
+    HIP_TRY(hipGetLastError());
+    double r = 0.0;
+    HIP_TRY(hipMemcpyAsync(&r, h->red, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *sigma = (double)(T)std::sqrt(r);
+    return PDLP_OK;
+}
+
+int check_problem(const pdlp_problem* p)
+{
+    if (!p) return PDLP_ERR_INVALID;
+    if (p->dtype != PDLP_F32 && p->dtype != PDLP_F64) return PDLP_ERR_INVALID;
+    if (p->m < 0 || p->n < 0 || p->m_ineq < 0 || p->m_ineq > p->m) return PDLP_ERR_INVALID;
+    if (p->row0 < 0 || p->row1 < p->row0 || p->row1 > p->m) return PDLP_ERR_INVALID;
+    if (p->col0 < 0 || p->col1 < p->col0 || p->col1 > p->n) return PDLP_ERR_INVALID;
+    if (p->m >= INT32_MAX || p->n >= INT32_MAX) return PDLP_ERR_INVALID;
+    return PDLP_OK;
+}
+
+struct Carve {
+    int64_t off = 0;
+    int64_t take(int64_t bytes) { const int64_t o = off; off = align_up(off + bytes, 256); return o; }
+};
+
+// one layout function used by both the size query and pdlp_create
+int64_t layout(const pdlp_problem* p, int64_t nnzK, int64_t nnzKT, int64_t* offs /*[24]*/)
+{
+    const int64_t es = p->dtype == PDLP_F32 ? 4 : 8;
+    const int64_t nl = p->col1 - p->col0, ml = p->row1 - p->row0;
+    Carve c;
+    int k = 0;
+    for (int i = 0; i < 3; ++i) offs[k++] = c.take(p->n * es);   // 0..2  xb
+    for (int i = 0; i < 3; ++i) offs[k++] = c.take(p->m * es);   // 3..5  yb
+    offs[k++] = c.take(p->n * es);                                // 6     xbar
+    offs[k++] = c.take(nl * es);                                  // 7     x_sum
+    offs[k++] = c.take(ml * es);                                  // 8     y_sum
+    offs[k++] = c.take(nl * es);                                  // 9     x_last
+    offs[k++] = c.take(ml * es);                                  // 10    y_last
+    for (int i = 0; i < 3; ++i) offs[k++] = c.take(ml * es);     // 11..13 kx caches
+    offs[k++] = c.take((int64_t)MAX_GRID * NACC * 8);             // 14    partA
+    offs[k++] = c.take((int64_t)MAX_GRID * NACC * 8);             // 15    partB
+    offs[k++] = c.take(PDLP_NRED * 8);                            // 16    red
+    offs[k++] = c.take(PDLP_NSCAL * 8);                           // 17    sc
+    offs[k++] = c.take((max_blocks(ml, nnzK) + 1) * 4);           // 18    schedule K
+    offs[k++] = c.take((max_blocks(nl, nnzKT) + 1) * 4);          // 19    schedule K'
+    return c.off;
+}
+
+int read_last_rowptr(const int32_t* rp, int64_t rows, int64_t* nnz)
+{
+    int32_t v = 0;
+    if (rows > 0) HIP_TRY(hipMemcpy(&v, rp + rows, sizeof(int32_t), hipMemcpyDeviceToHost));
+    *nnz = v;
+    return PDLP_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int pdlp_abi_version(void) { return 1; }
+
+const char* pdlp_strerror(int code)
+{
+    switch (code) {
+        case PDLP_OK: return "ok";
+        case PDLP_ERR_INVALID: return "invalid argument";
+        case PDLP_ERR_WORKSPACE: return "workspace too small or not 256-byte aligned";
+        case PDLP_ERR_STATE: return "call sequence violated";
+        default: break;
+    }
+    if (code <= PDLP_ERR_HIP_BASE) return hipGetErrorString((hipError_t)(PDLP_ERR_HIP_BASE - code));
+    return "unknown error";
+}
+
+int pdlp_workspace_bytes(const pdlp_problem* p, int64_t* bytes)
+{
+    int rc = check_problem(p);
+    if (rc != PDLP_OK || !bytes) return PDLP_ERR_INVALID;
+    HIP_TRY(hipSetDevice(p->device));
+    int64_t nnzK = 0, nnzKT = 0, offs[24];
+    if ((rc = read_last_rowptr(p->K_rowptr, p->row1 - p->row0, &nnzK)) != PDLP_OK) return rc;
+    if ((rc = read_last_rowptr(p->KT_rowptr, p->col1 - p->col0, &nnzKT)) != PDLP_OK) return rc;
+    *bytes = layout(p, nnzK, nnzKT, offs);
+    return PDLP_OK;
+}
+
+int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_t workspace_bytes)
+{
+    int rc = check_problem(p);
+    if (rc != PDLP_OK || !out) return PDLP_ERR_INVALID;
+    HIP_TRY(hipSetDevice(p->device));
+    const int64_t nl = p->col1 - p->col0, ml = p->row1 - p->row0;
+    std::vector<int32_t> rpK((size_t)ml + 1, 0), rpKT((size_t)nl + 1, 0);
+    if (ml > 0) HIP_TRY(hipMemcpy(rpK.data(), p->K_rowptr, (size_t)(ml + 1) * 4, hipMemcpyDeviceToHost));
+    if (nl > 0) HIP_TRY(hipMemcpy(rpKT.data(), p->KT_rowptr, (size_t)(nl + 1) * 4, hipMemcpyDeviceToHost));
+    if (rpK[0] != 0 || rpKT[0] != 0) return PDLP_ERR_INVALID;
+    int64_t offs[24];
+    const int64_t need = layout(p, rpK[ml], rpKT[nl], offs);
+    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255u)) return PDLP_ERR_WORKSPACE;
+
+    pdlp_solver* h = new (std::nothrow) pdlp_solver();
+    if (!h) return PDLP_ERR_INVALID;
+    h->p = *p;
+    h->stream = (hipStream_t)p->stream;
+    h->es = p->dtype == PDLP_F32 ? 4 : 8;
+    h->nl = nl;
+    h->ml = ml;
+    int64_t ie = p->m_ineq - p->row0;
+    h->ineq_end = (int)(ie < 0 ? 0 : (ie > ml ? ml : ie));
+    char* w = (char*)workspace;
+    for (int i = 0; i < 3; ++i) h->xb[i] = w + offs[i];
+    for (int i = 0; i < 3; ++i) h->yb[i] = w + offs[3 + i];
+    h->ix_cur = 0; h->ix_prev = 1; h->ix_avg = 2;
+    h->xbar = w + offs[6];
+    h->x_sum = w + offs[7]; h->y_sum = w + offs[8]; h->x_last = w + offs[9]; h->y_last = w + offs[10];
+    for (int i = 0; i < 3; ++i) h->kxb[i] = w + offs[11 + i];
+    h->partA = (double*)(w + offs[14]); h->partB = (double*)(w + offs[15]);
+    h->red = (double*)(w + offs[16]); h->sc = (double*)(w + offs[17]);
+    h->sK.blk = (int32_t*)(w + offs[18]); h->sKT.blk = (int32_t*)(w + offs[19]);
+    h->kx_valid = false; h->cand_valid[0] = h->cand_valid[1] = false;
+    h->last_gridA = h->last_gridB = 0;
+
+    std::vector<int32_t> sched;
+    build_schedule_host(rpK, ml, sched);
+    h->sK.nblk = ml > 0 ? (int)sched.size() - 1 : 0;
+    h->sK.grid = h->sK.nblk < MAX_GRID ? h->sK.nblk : MAX_GRID;
+    rc = hipMemcpy(h->sK.blk, sched.data(), sched.size() * 4, hipMemcpyHostToDevice) == hipSuccess ? PDLP_OK : PDLP_ERR_HIP_BASE - 1;
+    build_schedule_host(rpKT, nl, sched);
+    h->sKT.nblk = nl > 0 ? (int)sched.size() - 1 : 0;
+    h->sKT.grid = h->sKT.nblk < MAX_GRID ? h->sKT.nblk : MAX_GRID;
+    if (rc == PDLP_OK && hipMemcpy(h->sKT.blk, sched.data(), sched.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+        rc = PDLP_ERR_HIP_BASE - 1;
+    // zero every state vector, scratch and scalar (everything in front of the schedules)
+    if (rc == PDLP_OK && hipMemsetAsync(w, 0, (size_t)offs[18], h->stream) != hipSuccess) rc = PDLP_ERR_HIP_BASE - 1;
+    if (rc != PDLP_OK) { delete h; return rc; }
+    if (p->dtype == PDLP_F32) hipLaunchKernelGGL(k_set_step<float>, dim3(1), dim3(1), 0, h->stream, h->sc, 0.0, 1.0, 1.0, 0.0);
+    else hipLaunchKernelGGL(k_set_step<double>, dim3(1), dim3(1), 0, h->stream, h->sc, 0.0, 1.0, 1.0, 0.0);
+    *out = h;
+    return PDLP_OK;
+}
+
+void pdlp_destroy(pdlp_handle h)
+{
+    if (!h) return;
+    (void)hipStreamSynchronize(h->stream);
+    delete h;
+}
+
+int pdlp_buffer_ptr(pdlp_handle h, int which, void** ptr)
+{
+    if (!h || !ptr) return PDLP_ERR_INVALID;
+    switch (which) {
+        case PDLP_BUF_X_CUR: *ptr = h->xb[h->ix_cur]; break;
+        case PDLP_BUF_X_PREV: *ptr = h->xb[h->ix_prev]; break;
+        case PDLP_BUF_XBAR: *ptr = h->xbar; break;
+        case PDLP_BUF_X_AVG: *ptr = h->xb[h->ix_avg]; break;
+        case PDLP_BUF_Y_CUR: *ptr = h->yb[h->ix_cur]; break;
+        case PDLP_BUF_Y_PREV: *ptr = h->yb[h->ix_prev]; break;
+        case PDLP_BUF_Y_AVG: *ptr = h->yb[h->ix_avg]; break;
+        case PDLP_BUF_RED: *ptr = h->red; break;
+        case PDLP_BUF_X_SUM: *ptr = h->x_sum; break;
+        case PDLP_BUF_Y_SUM: *ptr = h->y_sum; break;
+        case PDLP_BUF_SCALARS: *ptr = h->sc; break;
+        default: return PDLP_ERR_INVALID;
+    }
+    return PDLP_OK;
+}
+
+int pdlp_set_iterate(pdlp_handle h, const void* x_local, const void* y_local)
+{
+    if (!h || !x_local || !y_local) return PDLP_ERR_INVALID;
+    HIP_TRY(hipMemcpyAsync(h->xb[h->ix_cur] + h->p.col0 * h->es, x_local, h->nl * h->es, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->yb[h->ix_cur] + h->p.row0 * h->es, y_local, h->ml * h->es, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->x_last, x_local, h->nl * h->es, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->y_last, y_local, h->ml * h->es, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipMemsetAsync(h->x_sum, 0, h->nl * h->es, h->stream));
+    HIP_TRY(hipMemsetAsync(h->y_sum, 0, h->ml * h->es, h->stream));
+    hipLaunchKernelGGL(k_reset_average, dim3(1), dim3(1), 0, h->stream, h->sc);
+    HIP_TRY(hipGetLastError());
+    h->kx_valid = false;
+    h->cand_valid[0] = h->cand_valid[1] = false;
+    return PDLP_OK;
+}
+
+int pdlp_get_iterate(pdlp_handle h, int which, void* x_local, void* y_local)
+{
+    if (!h) return PDLP_ERR_INVALID;
+    const int ix = which == PDLP_CUR ? h->ix_cur : (which == PDLP_AVG ? h->ix_avg : (which == PDLP_PREV ? h->ix_prev : -1));
+    if (ix < 0) return PDLP_ERR_INVALID;
+    if (x_local) HIP_TRY(hipMemcpyAsync(x_local, h->xb[ix] + h->p.col0 * h->es, h->nl * h->es, hipMemcpyDeviceToDevice, h->stream));
+    if (y_local) HIP_TRY(hipMemcpyAsync(y_local, h->yb[ix] + h->p.row0 * h->es, h->ml * h->es, hipMemcpyDeviceToDevice, h->stream));
+    return PDLP_OK;
+}
+
+int pdlp_set_step(pdlp_handle h, double eta, double omega, double theta, int64_t iteration)
+{
+    if (!h || !(omega > 0.0)) return PDLP_ERR_INVALID;
+    if (h->p.dtype == PDLP_F32)
+        hipLaunchKernelGGL(k_set_step<float>, dim3(1), dim3(1), 0, h->stream, h->sc, eta, omega, theta, (double)iteration);
+    else
+        hipLaunchKernelGGL(k_set_step<double>, dim3(1), dim3(1), 0, h->stream, h->sc, eta, omega, theta, (double)iteration);
+    HIP_TRY(hipGetLastError());
+    return PDLP_OK;
+}
+
+int pdlp_set_omega(pdlp_handle h, double omega)
+{
+    if (!h || !(omega > 0.0)) return PDLP_ERR_INVALID;
+    if (h->p.dtype == PDLP_F32) hipLaunchKernelGGL(k_set_omega<float>, dim3(1), dim3(1), 0, h->stream, h->sc, omega);
+    else hipLaunchKernelGGL(k_set_omega<double>, dim3(1), dim3(1), 0, h->stream, h->sc, omega);
+    HIP_TRY(hipGetLastError());
+    return PDLP_OK;
+}
+
+int pdlp_get_scalars(pdlp_handle h, double out[PDLP_NSCAL])
+{
+    if (!h || !out) return PDLP_ERR_INVALID;
+    HIP_TRY(hipMemcpyAsync(out, h->sc, PDLP_NSCAL * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PDLP_OK;
+}
+
+int pdlp_primal_half(pdlp_handle h, int adaptive)
+{
+    if (!h) return PDLP_ERR_INVALID;
+    return DISPATCH(h, primal_half_t, h, adaptive);
+}
+
+int pdlp_dual_half(pdlp_handle h, int adaptive)
+{
+    if (!h) return PDLP_ERR_INVALID;
+    return DISPATCH(h, dual_half_t, h, adaptive);
+}
+
+int pdlp_adaptive_reduce(pdlp_handle h)
+{
+    if (!h) return PDLP_ERR_INVALID;
+    if (h->p.dtype == PDLP_F32)
+        hipLaunchKernelGGL(k_adaptive_reduce_update<float>, dim3(1), dim3(BLOCK), 0, h->stream, h->partA, h->last_gridA, h->partB,
+                           h->last_gridB, h->red, h->sc, 0);
+    else
+        hipLaunchKernelGGL(k_adaptive_reduce_update<double>, dim3(1), dim3(BLOCK), 0, h->stream, h->partA, h->last_gridA, h->partB,
+                           h->last_gridB, h->red, h->sc, 0);
+    HIP_TRY(hipGetLastError());
+    return PDLP_OK;
+}
+
+int pdlp_adaptive_update(pdlp_handle h)
+{
+    if (!h) return PDLP_ERR_INVALID;
+    if (h->p.dtype == PDLP_F32) hipLaunchKernelGGL(k_adaptive_update<float>, dim3(1), dim3(1), 0, h->stream, h->sc, h->red);
+    else hipLaunchKernelGGL(k_adaptive_update<double>, dim3(1), dim3(1), 0, h->stream, h->sc, h->red);
+    HIP_TRY(hipGetLastError());
+    return PDLP_OK;
+}
+
+int pdlp_iterate(pdlp_handle h, int iters, int adaptive)
+{
+    if (!h || iters < 0) return PDLP_ERR_INVALID;
+    if (h->nl != h->p.n || h->ml != h->p.m) return PDLP_ERR_STATE;   // sharded problems need the caller's exchange
+    int rc;
+    for (int it = 0; it < iters; ++it) {
+        if ((rc = pdlp_primal_half(h, adaptive)) != PDLP_OK) return rc;
+        if ((rc = pdlp_dual_half(h, adaptive)) != PDLP_OK) return rc;
+        if (adaptive) {
+            if (h->p.dtype == PDLP_F32)
+                hipLaunchKernelGGL(k_adaptive_reduce_update<float>, dim3(1), dim3(BLOCK), 0, h->stream, h->partA, h->last_gridA,
+                                   h->partB, h->last_gridB, h->red, h->sc, 1);
+            else
+                hipLaunchKernelGGL(k_adaptive_reduce_update<double>, dim3(1), dim3(BLOCK), 0, h->stream, h->partA, h->last_gridA,
+                                   h->partB, h->last_gridB, h->red, h->sc, 1);
+        }
+    }
+    if (!adaptive && iters > 0) {
+        if (h->p.dtype == PDLP_F32) hipLaunchKernelGGL(k_fixed_advance<float>, dim3(1), dim3(1), 0, h->stream, h->sc, iters);
+        else hipLaunchKernelGGL(k_fixed_advance<double>, dim3(1), dim3(1), 0, h->stream, h->sc, iters);
+    }
+    HIP_TRY(hipGetLastError());
+    return PDLP_OK;
+}
+
+int pdlp_fixed_advance(pdlp_handle h, int iters)
+{
+    if (!h || iters < 0) return PDLP_ERR_INVALID;
+    if (h->p.dtype == PDLP_F32) hipLaunchKernelGGL(k_fixed_advance<float>, dim3(1), dim3(1), 0, h->stream, h->sc, iters);
+    else hipLaunchKernelGGL(k_fixed_advance<double>, dim3(1), dim3(1), 0, h->stream, h->sc, iters);
+    HIP_TRY(hipGetLastError());
+    return PDLP_OK;
+}
+
+int pdlp_flush_average(pdlp_handle h)
+{
+    if (!h) return PDLP_ERR_INVALID;
+    return DISPATCH(h, flush_t, h);
+}
+
+int pdlp_compute_average(pdlp_handle h)
+{
+    if (!h) return PDLP_ERR_INVALID;
+    return DISPATCH(h, average_t, h);
+}
+
+int pdlp_kkt_local(pdlp_handle h, int which, int unscaled)
+{
+    if (!h || which < PDLP_CUR || which > PDLP_PREV) return PDLP_ERR_INVALID;
+    if (unscaled && (!h->p.d_col || !h->p.d_row)) return PDLP_ERR_STATE;
+    return DISPATCH(h, kkt_local_t, h, which, unscaled);
+}
+
+int pdlp_read_red(pdlp_handle h, double out[PDLP_NRED])
+{
+    if (!h || !out) return PDLP_ERR_INVALID;
+    HIP_TRY(hipMemcpyAsync(out, h->red, PDLP_NRED * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PDLP_OK;
+}
+
+int pdlp_kkt_finish(pdlp_handle h, double omega, double out[6])
+{
+    if (!h || !out) return PDLP_ERR_INVALID;
+    double r[PDLP_NRED];
+    int rc = pdlp_read_red(h, r);
+    if (rc != PDLP_OK) return rc;
+    if (h->p.dtype == PDLP_F32) kkt_finish_t<float>(r, omega, out);
+    else kkt_finish_t<double>(r, omega, out);
+    return PDLP_OK;
+}
+
+int pdlp_restart(pdlp_handle h, int which)
+{
+    if (!h || (which != PDLP_CUR && which != PDLP_AVG)) return PDLP_ERR_INVALID;
+    const int cand = which == PDLP_CUR ? 0 : 1;
+    if (which == PDLP_AVG) {       // the averaged iterate becomes current (pdhg.py:133,137,141)
+        const int t = h->ix_cur;
+        h->ix_cur = h->ix_avg;
+        h->ix_avg = t;
+    }
+    if (h->cand_valid[cand]) {     // K x of the chosen point was produced by its KKT pass
+        char* t = h->kxb[0];
+        h->kxb[0] = h->kxb[1 + cand];
+        h->kxb[1 + cand] = t;
+        h->kx_valid = true;
+    } else {
+        h->kx_valid = false;
+    }
+    h->cand_valid[0] = h->cand_valid[1] = false;
+    HIP_TRY(hipMemsetAsync(h->x_sum, 0, h->nl * h->es, h->stream));          // pdhg.py:58-60
+    HIP_TRY(hipMemsetAsync(h->y_sum, 0, h->ml * h->es, h->stream));
+    hipLaunchKernelGGL(k_reset_average, dim3(1), dim3(1), 0, h->stream, h->sc);
+    HIP_TRY(hipGetLastError());
+    return PDLP_OK;
+}
+
+int pdlp_restart_distance_local(pdlp_handle h)
+{
+    if (!h) return PDLP_ERR_INVALID;
+    return DISPATCH(h, distance_t, h);
+}
+
+int pdlp_mark_restart_point(pdlp_handle h)
+{
+    if (!h) return PDLP_ERR_INVALID;                                          // pdhg.py:63-64
+    HIP_TRY(hipMemcpyAsync(h->x_last, h->xb[h->ix_cur] + h->p.col0 * h->es, h->nl * h->es, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->y_last, h->yb[h->ix_cur] + h->p.row0 * h->es, h->ml * h->es, hipMemcpyDeviceToDevice, h->stream));
+    return PDLP_OK;
+}
+
+int pdlp_spmv(pdlp_handle h, int transpose, const void* in_full, void* out_local)
+{
+    if (!h || !in_full || !out_local) return PDLP_ERR_INVALID;
+    return DISPATCH(h, spmv_t, h, transpose, in_full, out_local);
+}
+
+int pdlp_power_iteration(pdlp_handle h, const void* b0, int iters, void* work_n, void* work_m, double* sigma)
+{
+    if (!h || !b0 || !work_n || !work_m || !sigma || iters < 0) return PDLP_ERR_INVALID;
+    if (h->nl != h->p.n || h->ml != h->p.m) return PDLP_ERR_STATE;
+    return DISPATCH(h, power_iteration_t, h, b0, iters, work_n, work_m, sigma);
+}
+
+// ---- Ruiz building blocks -------------------------------------------------------------------------
+int pdlp_csr_row_scale_factors(int dtype, int64_t rows, const int32_t* rowptr, const void* val, double eps, void* norm, void* stream)
+{
+    if (rows < 0 || (dtype != PDLP_F32 && dtype != PDLP_F64)) return PDLP_ERR_INVALID;
+    if (rows == 0) return PDLP_OK;
+    const int g = grid_for(rows * 8);
+    if (dtype == PDLP_F32)
+        hipLaunchKernelGGL(k_row_scale_factors<float>, dim3(g), dim3(BLOCK), 0, (hipStream_t)stream, rows, rowptr, (const float*)val,
+                           (float)eps, (float*)norm);
+    else
+        hipLaunchKernelGGL(k_row_scale_factors<double>, dim3(g), dim3(BLOCK), 0, (hipStream_t)stream, rows, rowptr, (const double*)val,
+                           eps, (double*)norm);
+    HIP_TRY(hipGetLastError());
+    return PDLP_OK;
+}
+
+int pdlp_csr_div_rows(int dtype, int64_t rows, const int32_t* rowptr, void* val, const void* norm, void* stream)
+{
+    if (rows < 0 || (dtype != PDLP_F32 && dtype != PDLP_F64)) return PDLP_ERR_INVALID;
+    if (rows == 0) return PDLP_OK;
+    const int g = grid_for(rows * 8);
+    if (dtype == PDLP_F32)
+        hipLaunchKernelGGL(k_div_rows<float>, dim3(g), dim3(BLOCK), 0, (hipStream_t)stream, rows, rowptr, (float*)val, (const float*)norm);
+    else
+        hipLaunchKernelGGL(k_div_rows<double>, dim3(g), dim3(BLOCK), 0, (hipStream_t)stream, rows, rowptr, (double*)val, (const double*)norm);
+    HIP_TRY(hipGetLastError());
+    return PDLP_OK;
+}
+
+int pdlp_csr_div_cols(int dtype, int64_t rows, const int32_t* rowptr, const int32_t* colidx, void* val, const void* norm_full, void* stream)
+{
+    if (rows < 0 || (dtype != PDLP_F32 && dtype != PDLP_F64)) return PDLP_ERR_INVALID;
+    if (rows == 0) return PDLP_OK;
+    int32_t nnz = 0;
+    HIP_TRY(hipMemcpy(&nnz, rowptr + rows, 4, hipMemcpyDeviceToHost));
+    if (nnz == 0) return PDLP_OK;
+    const int g = grid_for(nnz);
+    if (dtype == PDLP_F32)
+        hipLaunchKernelGGL(k_div_cols<float>, dim3(g), dim3(BLOCK), 0, (hipStream_t)stream, (int64_t)nnz, colidx, (float*)val,
+                           (const float*)norm_full);
+    else
+        hipLaunchKernelGGL(k_div_cols<double>, dim3(g), dim3(BLOCK), 0, (hipStream_t)stream, (int64_t)nnz, colidx, (double*)val,
+                           (const double*)norm_full);
+    HIP_TRY(hipGetLastError());
+    return PDLP_OK;
+}
+
+int pdlp_vec_muldiv(int dtype, int64_t len, void* a, const void* b, int op, void* stream)
+{
+    if (len < 0 || (dtype != PDLP_F32 && dtype != PDLP_F64) || (op != 0 && op != 1)) return PDLP_ERR_INVALID;
+    if (len == 0) return PDLP_OK;
+    if (dtype == PDLP_F32)
+        hipLaunchKernelGGL(k_muldiv<float>, dim3(grid_for(len)), dim3(BLOCK), 0, (hipStream_t)stream, len, (float*)a, (const float*)b, op);
+    else
+        hipLaunchKernelGGL(k_muldiv<double>, dim3(grid_for(len)), dim3(BLOCK), 0, (hipStream_t)stream, len, (double*)a, (const double*)b, op);
+    HIP_TRY(hipGetLastError());
+    return PDLP_OK;
+}
+
+int pdlp_vec_max_dev_from_one(int dtype, int64_t len, const void* v, void* work8, double* out, void* stream)
+{
+    if (len < 0 || !work8 || !out || (dtype != PDLP_F32 && dtype != PDLP_F64)) return PDLP_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(work8, 0, 8, s));
+    if (len > 0) {
+        if (dtype == PDLP_F32)
+            hipLaunchKernelGGL(k_max_dev_from_one<float>, dim3(grid_for(len)), dim3(BLOCK), 0, s, len, (const float*)v, (double*)work8);
+        else
+            hipLaunchKernelGGL(k_max_dev_from_one<double>, dim3(grid_for(len)), dim3(BLOCK), 0, s, len, (const double*)v, (double*)work8);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(out, work8, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return PDLP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,248 @@
+"""PdlpEngine: one LP (or one rank's shard of it) resident on one MI355X, driven through the C ABI.
+
+torch is used for storage (problem arrays, one workspace tensor) and, when the problem is sharded
+over several GPUs, for the collectives between the half-steps (``torch.distributed`` backend
+``nccl`` = RCCL over xGMI).  All arithmetic of the hot path happens in ``libpdlp_hip.so``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _native as N
+from .sparse import CsrPair, as_vec
+
+_DT = {torch.float32: N.PDLP_F32, torch.float64: N.PDLP_F64}
+
+
+class Comm:
+    """One process per GPU.  Vectors are sharded in equal blocks (the LP is padded so the sizes divide)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+
+    def all_gather(self, full: torch.Tensor):
+        """full = concat over ranks of equal shards; this rank's shard is already in place."""
+        shard = full.numel() // self.world
+        mine = full[self.rank * shard:(self.rank + 1) * shard]
+        if self.backend == "gloo" and full.is_cuda:     # test path: gloo has no device all-gather
+            host = torch.empty(full.numel(), dtype=full.dtype)
+            self.dist.all_gather_into_tensor(host, mine.cpu(), group=self.group)
+            full.copy_(host)
+        else:
+            self.dist.all_gather_into_tensor(full, mine, group=self.group)
+
+    def all_reduce_sum(self, t: torch.Tensor):
+        if self.backend == "gloo" and t.is_cuda:
+            host = t.cpu()
+            self.dist.all_reduce(host, group=self.group)
+            t.copy_(host)
+        else:
+            self.dist.all_reduce(t, group=self.group)
+
+
+class PdlpEngine:
+    """Device-resident restarted-PDHG state for one LP shard.
+
+    Parameters are this rank's blocks: ``K_rows`` = CSR of rows [row0,row1) of K, ``KT_rows`` = CSR of
+    rows [col0,col1) of K' (global indices), ``c,l,u`` of length col1-col0, ``q`` of length row1-row0.
+    """
+
+    def __init__(self, m: int, n: int, m_ineq: int, K_rows, KT_rows, c, q, l, u, rows: Tuple[int, int] = None,
+                 cols: Tuple[int, int] = None, d_col=None, d_row=None, comm: Optional[Comm] = None):
+        self.lib = N.load()
+        rows = (0, m) if rows is None else rows
+        cols = (0, n) if cols is None else cols
+        self.m, self.n, self.m_ineq = int(m), int(n), int(m_ineq)
+        self.rows, self.cols = (int(rows[0]), int(rows[1])), (int(cols[0]), int(cols[1]))
+        self.ml, self.nl = self.rows[1] - self.rows[0], self.cols[1] - self.cols[0]
+        self.comm = comm if (comm is not None and comm.world > 1) else None
+        if self.comm is None and (self.ml != self.m or self.nl != self.n):
+            raise ValueError("a sharded problem needs a communicator")
+        val = K_rows[2]
+        self.device, self.dtype = val.device, val.dtype
+        if self.device.type != "cuda":
+            raise N.PdlpError("PdlpEngine needs the problem on a HIP device (there is no CPU fallback)")
+        if self.dtype not in _DT:
+            raise ValueError(f"unsupported dtype {self.dtype}")
+        i32 = lambda t: t.to(device=self.device, dtype=torch.int32).contiguous()
+        fv = lambda t, ln: None if t is None else as_vec(t, ln, self.device, self.dtype)
+        # keep every tensor the library points into alive
+        self.K = (i32(K_rows[0]), i32(K_rows[1]), K_rows[2].to(self.dtype).contiguous())
+        self.KT = (i32(KT_rows[0]), i32(KT_rows[1]), KT_rows[2].to(self.device, self.dtype).contiguous())
+        self.c, self.l, self.u = fv(c, self.nl), fv(l, self.nl), fv(u, self.nl)
+        self.q = fv(q, self.ml)
+        self.d_col, self.d_row = fv(d_col, self.nl), fv(d_row, self.ml)
+        self.stream = torch.cuda.current_stream(self.device)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        self.prob = N.PdlpProblem(_DT[self.dtype], self.device.index or 0, self.m, self.n, self.m_ineq,
+                                  self.rows[0], self.rows[1], self.cols[0], self.cols[1],
+                                  ptr(self.K[0]), ptr(self.K[1]), ptr(self.K[2]),
+                                  ptr(self.KT[0]), ptr(self.KT[1]), ptr(self.KT[2]),
+                                  ptr(self.c), ptr(self.l), ptr(self.u), ptr(self.q), ptr(self.d_col), ptr(self.d_row),
+                                  self.stream.cuda_stream)
+        nbytes = C.c_int64(0)
+        N.check(self.lib.pdlp_workspace_bytes(C.byref(self.prob), C.byref(nbytes)), "pdlp_workspace_bytes")
+        self.workspace = torch.empty(int(nbytes.value) + 256, dtype=torch.uint8, device=self.device)
+        self._ws_off = (-self.workspace.data_ptr()) % 256
+        self.h = N._H()
+        N.check(self.lib.pdlp_create(C.byref(self.h), C.byref(self.prob), self.workspace.data_ptr() + self._ws_off,
+                                     nbytes.value), "pdlp_create")
+        self._views = {}
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            self.lib.pdlp_destroy(h)
+
+    @classmethod
+    def from_full(cls, K: CsrPair, c, q, l, u, m_ineq: int, d_col=None, d_row=None) -> "PdlpEngine":
+        """single-GPU engine over a whole problem"""
+        return cls(K.m, K.n, m_ineq, (K.rowptr, K.colidx, K.val), (K.t_rowptr, K.t_colidx, K.t_val), c, q, l, u,
+                   d_col=d_col, d_row=d_row)
+
+    # ---- buffers ------------------------------------------------------------------------------------
+    def buffer(self, which: int) -> torch.Tensor:
+        """torch view of one of the library's device buffers (roles move: query again after a step)"""
+        p = C.c_void_p()
+        N.check(self.lib.pdlp_buffer_ptr(self.h, which, C.byref(p)), "pdlp_buffer_ptr")
+        key = (p.value, which in (N.BUF_RED, N.BUF_SCALARS))
+        v = self._views.get(key)
+        if v is None:
+            off = p.value - self.workspace.data_ptr()
+            if which in (N.BUF_RED, N.BUF_SCALARS):
+                cnt = N.NRED if which == N.BUF_RED else N.NSCAL
+                v = self.workspace[off:off + cnt * 8].view(torch.float64)
+            else:
+                ln = {N.BUF_X_SUM: self.nl, N.BUF_Y_SUM: self.ml}.get(
+                    which, self.n if which <= N.BUF_X_AVG else self.m)
+                v = self.workspace[off:off + ln * self.dtype.itemsize].view(self.dtype)
+            self._views[key] = v
+        return v
+
+    def _gather(self, which: int):
+        if self.comm is not None:
+            self.comm.all_gather(self.buffer(which))
+
+    # ---- state --------------------------------------------------------------------------------------
+    def set_iterate(self, x_local: torch.Tensor, y_local: torch.Tensor):
+        x = as_vec(x_local, self.nl, self.device, self.dtype)
+        y = as_vec(y_local, self.ml, self.device, self.dtype)
+        N.check(self.lib.pdlp_set_iterate(self.h, x.data_ptr(), y.data_ptr()), "pdlp_set_iterate")
+        self._gather(N.BUF_X_CUR)
+        self._gather(N.BUF_Y_CUR)
+
+    def get_iterate(self, which: int = N.CUR) -> Tuple[torch.Tensor, torch.Tensor]:
+        x = torch.empty(self.nl, dtype=self.dtype, device=self.device)
+        y = torch.empty(self.ml, dtype=self.dtype, device=self.device)
+        N.check(self.lib.pdlp_get_iterate(self.h, which, x.data_ptr(), y.data_ptr()), "pdlp_get_iterate")
+        return x, y
+
+    def set_step(self, eta: float, omega: float, theta: float = 1.0, iteration: int = 0):
+        N.check(self.lib.pdlp_set_step(self.h, float(eta), float(omega), float(theta), int(iteration)), "pdlp_set_step")
+
+    def set_omega(self, omega: float):
+        N.check(self.lib.pdlp_set_omega(self.h, float(omega)), "pdlp_set_omega")
+
+    def scalars(self) -> dict:
+        out = (C.c_double * N.NSCAL)()
+        N.check(self.lib.pdlp_get_scalars(self.h, out), "pdlp_get_scalars")
+        names = ("eta", "omega", "theta", "tau", "sigma", "w_pending", "eta_sum", "k", "inv1pt", "accepted", "eta_bar",
+                 "denominator")
+        return {k: out[i] for i, k in enumerate(names)}
+
+    # ---- iterations ---------------------------------------------------------------------------------
+    def iterate(self, iters: int, adaptive: bool):
+        """`iters` PDHG iterations, no host synchronisation (pdhg.py:76-112)."""
+        if self.comm is None:
+            N.check(self.lib.pdlp_iterate(self.h, int(iters), int(adaptive)), "pdlp_iterate")
+            return
+        a = int(adaptive)
+        for _ in range(int(iters)):
+            N.check(self.lib.pdlp_primal_half(self.h, a), "pdlp_primal_half")
+            self._gather(N.BUF_XBAR)                       # K xbar needs every rank's block of xbar
+            N.check(self.lib.pdlp_dual_half(self.h, a), "pdlp_dual_half")
+            self._gather(N.BUF_Y_CUR)                      # the next K'y needs every rank's block of y
+            if adaptive:
+                N.check(self.lib.pdlp_adaptive_reduce(self.h), "pdlp_adaptive_reduce")
+                self.comm.all_reduce_sum(self.buffer(N.BUF_RED))
+                N.check(self.lib.pdlp_adaptive_update(self.h), "pdlp_adaptive_update")
+        if not adaptive and iters > 0:
+            N.check(self.lib.pdlp_fixed_advance(self.h, int(iters)), "pdlp_fixed_advance")
+
+    # ---- restart machinery --------------------------------------------------------------------------
+    def flush_average(self):
+        N.check(self.lib.pdlp_flush_average(self.h), "pdlp_flush_average")
+
+    def compute_average(self):
+        N.check(self.lib.pdlp_compute_average(self.h), "pdlp_compute_average")
+
+    def kkt(self, which: int, omega: float, unscaled: bool = False) -> dict:
+        """compute_residuals_and_duality_gap + KKT_error at CUR / AVG / PREV (helpers.py:53-108)."""
+        if self.comm is not None:
+            self._gather({N.CUR: N.BUF_X_CUR, N.AVG: N.BUF_X_AVG, N.PREV: N.BUF_X_PREV}[which])
+            self._gather({N.CUR: N.BUF_Y_CUR, N.AVG: N.BUF_Y_AVG, N.PREV: N.BUF_Y_PREV}[which])
+        N.check(self.lib.pdlp_kkt_local(self.h, which, int(unscaled)), "pdlp_kkt_local")
+        if self.comm is not None:
+            self.comm.all_reduce_sum(self.buffer(N.BUF_RED))
+        out = (C.c_double * 6)()
+        N.check(self.lib.pdlp_kkt_finish(self.h, float(omega), out), "pdlp_kkt_finish")
+        return dict(pr=out[0], dr=out[1], gap=out[2], p=out[3], d_adj=out[4], kkt=out[5])
+
+    def restart(self, which: int):
+        N.check(self.lib.pdlp_restart(self.h, which), "pdlp_restart")
+
+    def restart_distance(self) -> Tuple[float, float]:
+        """(||x - x_last_restart||^2, ||y - y_last_restart||^2) over all ranks (enhancements.py:74-75)"""
+        N.check(self.lib.pdlp_restart_distance_local(self.h), "pdlp_restart_distance_local")
+        if self.comm is not None:
+            self.comm.all_reduce_sum(self.buffer(N.BUF_RED))
+        out = (C.c_double * N.NRED)()
+        N.check(self.lib.pdlp_read_red(self.h, out), "pdlp_read_red")
+        return out[0], out[1]
+
+    def mark_restart_point(self):
+        N.check(self.lib.pdlp_mark_restart_point(self.h), "pdlp_mark_restart_point")
+
+    # ---- products -----------------------------------------------------------------------------------
+    def spmv(self, v_full: torch.Tensor, transpose: bool = False) -> torch.Tensor:
+        """K v (or K' v) for this rank's rows; ``v_full`` must be complete."""
+        v = as_vec(v_full, self.m if transpose else self.n, self.device, self.dtype)
+        out = torch.empty(self.nl if transpose else self.ml, dtype=self.dtype, device=self.device)
+        N.check(self.lib.pdlp_spmv(self.h, int(transpose), v.data_ptr(), out.data_ptr()), "pdlp_spmv")
+        return out
+
+    def power_iteration(self, b0: torch.Tensor, iters: int = 100) -> float:
+        """spectral_norm_estimate_torch (helpers.py:41-51) with the start vector given."""
+        b0 = as_vec(b0, self.n, self.device, self.dtype)
+        if self.comm is None:
+            wn = torch.empty(self.n, dtype=self.dtype, device=self.device)
+            wm = torch.empty(self.m, dtype=self.dtype, device=self.device)
+            s = C.c_double(0)
+            N.check(self.lib.pdlp_power_iteration(self.h, b0.data_ptr(), int(iters), wn.data_ptr(), wm.data_ptr(), C.byref(s)),
+                    "pdlp_power_iteration")
+            return s.value
+        # sharded: the same recurrence with the exchange between the two products (setup, runs once)
+        b = b0.clone()
+        t = torch.zeros(self.m, dtype=self.dtype, device=self.device)
+        r0, r1 = self.rows
+        c0, c1 = self.cols
+        for _ in range(int(iters)):
+            t[r0:r1] = self.spmv(b, False)
+            self.comm.all_gather(t)
+            b[c0:c1] = self.spmv(t, True)
+            self.comm.all_gather(b)
+            b /= torch.linalg.norm(b)
+        t[r0:r1] = self.spmv(b, False)
+        self.comm.all_gather(t)
+        return float(torch.linalg.norm(t))
+
+    def synchronize(self):
+        self.stream.synchronize()
