@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""PDHG iterations/sec on a synthetic sparse LP (BASELINE.json metric), 1..8 MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one PDHG iteration of the production driver (torchpdlp_amd.solver.PdhgDriver): the two
+fused SpMV half-steps (+ the step-size rule when adaptive) with the reference's restart cadence inside
+the timed region -- three KKT evaluations every 40 iterations and the restart work when one fires.
+The LP is resident in HBM before the clock starts.  Default workload = the one the metric is quoted
+on: 10M x 10M, density 1e-5 (100 non-zeros per row), float32 like the reference; it fits one GPU.
+With N > 1 the same instance is sharded (row blocks of K and K'), so scaling is strong.
+
+Also reports, in the same JSON line:
+  roofline     algorithmic HBM bytes of the dominant kernel per launch / its mean duration (HIP events)
+  cpu_baseline the CPU oracle (C port, OpenMP) on a bounded sample of the same workload, rank 0, N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torchpdlp_amd as tp                                     # noqa: E402
+from torchpdlp_amd import _native as N                         # noqa: E402
+from torchpdlp_amd.distributed import shard_engine             # noqa: E402
+from torchpdlp_amd.solver import PdhgDriver, estimate_sigma    # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=40)
+    p.add_argument("--n", type=int, default=int(os.environ.get("PDLP_BENCH_N", 10_000_000)))
+    p.add_argument("--m", type=int, default=None)
+    p.add_argument("--nnz-per-row", type=int, default=int(os.environ.get("PDLP_BENCH_NNZ", 100)))
+    p.add_argument("--mode", choices=["adaptive", "fixed"], default="adaptive")
+    p.add_argument("--dtype", choices=["f32", "f64"], default="f32")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample-rows", type=int, default=500_000)
+    p.add_argument("--kernel-reps", type=int, default=10)
+    return p.parse_args()
+
+
+def algorithmic_bytes(n, m, nnz, sv, si, adaptive):
+    """SURVEY.md section 8d, per launch of each half-step kernel (each array counted once)."""
+    primal = nnz * (sv + si) + (n + 1) * si + m * sv + 8 * n * sv          # K' stream, gather y, x c l u | x+ xbar | sum RMW
+    dual = nnz * (sv + si) + (m + 1) * si + n * sv + 5 * m * sv            # K stream, gather xbar, y q | y+ | sum RMW
+    if adaptive:
+        dual += 2 * m * sv                                                 # cached K x read + write
+    return primal, dual
+
+
+def time_kernel(eng, fn, reps):
+    """mean duration (ms) of one launch, HIP events on the stream the kernel runs on"""
+    stream = eng.stream
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    fn()
+    stream.synchronize()
+    for a, b in evs:
+        a.record(stream)
+        fn()
+        b.record(stream)
+    stream.synchronize()
+    return sum(a.elapsed_time(b) for a, b in evs) / reps
+
+
+def cpu_baseline(args, sv_dtype):
+    """The CPU oracle (oracle/, a C restatement of the reference pinned by tests/golden) timed on the host
+    cores of this box on a bounded sample: the same generator with fewer rows/columns and the same
+    non-zeros per row; the rate is scaled by non-zero count to the full workload (SpMV dominated)."""
+    from oracle import oracle as orc       # checker/baseline only -- never on the product path
+    import numpy as np
+    rows = min(args.cpu_sample_rows, args.n)
+    lp = tp.gen_lp(rows, rows, args.nnz_per_row, seed=0, device="cuda", dtype=sv_dtype)
+    K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
+    h = lambda t: t.cpu().numpy()
+    o = orc.OracleLP(lp.m, lp.n, lp.m_ineq, h(K.rowptr), h(K.colidx), h(K.val), h(lp.c), h(lp.q), h(lp.l), h(lp.u),
+                     dtype=np.float32 if sv_dtype == torch.float32 else np.float64,
+                     trans=(h(K.t_rowptr), h(K.t_colidx), h(K.t_val)))
+    cores = orc.set_threads(os.cpu_count() or 1)
+    x, y = np.zeros(lp.n, o.dtype), np.zeros(lp.m, o.dtype)
+    eta, om = o.dtype.type(0.01), o.dtype.type(1.0)
+    adaptive = args.mode == "adaptive"
+
+    def one(k, x, y, eta):
+        if adaptive:
+            x, y, _, eta, _ = o.step_adaptive(x, y, eta, om, 1.0, k)
+        else:
+            x, y = o.step_fixed(x, y, eta, om, 1.0)
+        return x, y, eta
+    x, y, eta = one(1, x, y, eta)
+    t0, iters = time.time(), 0
+    while iters < 3 or (time.time() - t0 < 10.0 and iters < 200):
+        x, y, eta = one(iters + 2, x, y, eta)
+        iters += 1
+    step_s = (time.time() - t0) / iters
+    t1 = time.time()
+    o.kkt(x, y, om)
+    kkt_s = time.time() - t1
+    per_iter = step_s + 3.0 * kkt_s / 40.0            # the reference's restart cadence
+    scale = (lp.nnz / float(args.nnz_per_row * (args.m or args.n)))
+    return dict(value=round(scale / per_iter, 4), unit="iterations/s", cores=cores, kind="port",
+                sample=f"oracle (C, OpenMP) on gen_lp({rows}x{rows}, {args.nnz_per_row} nnz/row, seed 0): "
+                       f"{iters} {args.mode} iterations at {step_s * 1e3:.1f} ms + KKT pass {kkt_s * 1e3:.1f} ms x3/40; "
+                       f"rate scaled by nnz ratio {scale:.4g} to the full workload")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+        comm = tp.Comm()
+    m = args.m or args.n
+    dt = torch.float32 if args.dtype == "f32" else torch.float64
+    adaptive = args.mode == "adaptive"
+
+    t_setup = time.time()
+    lp = tp.gen_lp(args.n, m, args.nnz_per_row, seed=0, device=dev, dtype=dt)
+    K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
+    nnz = K.nnz
+    eng = shard_engine(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq, comm)
+    if comm is not None:            # every rank generated the whole seeded instance; keep only the block
+        del K, lp
+        torch.cuda.empty_cache()
+    drv = PdhgDriver(eng, restart_period=40, primal_update=True, adaptive=adaptive, tol=1e-4)
+    sigma = estimate_sigma(eng, power_iters=20, seed=0)
+    drv.start(sigma)
+    setup_s = time.time() - t_setup
+
+    def run(iters):
+        done = 0
+        while done < iters:
+            done += drv.advance(iters - done)
+
+    def fence():
+        if comm is not None:
+            comm.dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    fence()
+    t0 = time.time()
+    run(args.steps)
+    fence()
+    elapsed = time.time() - t0
+    if comm is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        comm.dist.all_reduce(tt, op=comm.dist.ReduceOp.MAX)
+        elapsed = float(tt)
+
+    # ---- roofline of the dominant kernel (per launch, this rank's shard) ---------------------------
+    sv, si = (4 if dt == torch.float32 else 8), 4
+    nl, ml = eng.nl, eng.ml
+    nnz_k = int(eng.K[2].numel())
+    nnz_kt = int(eng.KT[2].numel())
+    b_primal, _ = algorithmic_bytes(nl, eng.m, nnz_kt, sv, si, adaptive)
+    _, b_dual = algorithmic_bytes(eng.n, ml, nnz_k, sv, si, adaptive)
+    a = int(adaptive)
+    ms_primal = time_kernel(eng, lambda: N.check(eng.lib.pdlp_primal_half(eng.h, a)), args.kernel_reps)
+    # the dual kernel flips the iterate buffers each launch: harmless for timing
+    ms_dual = time_kernel(eng, lambda: N.check(eng.lib.pdlp_dual_half(eng.h, a)), args.kernel_reps)
+    if ms_primal >= ms_dual:
+        kname, kms, kbytes = "k_csr_fused<PrimalEpi> (K'y + primal update)", ms_primal, b_primal
+    else:
+        kname, kms, kbytes = "k_csr_fused<DualEpi> (K xbar + dual update)", ms_dual, b_dual
+    achieved = kbytes / (kms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")       # rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, see profiles/README.md
+    if os.path.exists(tfile):
+        try:
+            tj = json.load(open(tfile))
+            key = f"n{args.n}_k{args.nnz_per_row}_{args.dtype}_{args.mode}_g{world}"
+            traffic = tj.get(key, {}).get("primal" if ms_primal >= ms_dual else "dual")
+        except Exception:
+            traffic = None
+    roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, launch_ms=round(kms, 4),
+                    algorithmic_bytes=int(kbytes), other_kernel_ms=round(min(ms_primal, ms_dual), 4))
+
+    out = {
+        "metric": "PDHG iterations/sec", "value": round(args.steps / elapsed, 3), "unit": "iterations/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"synthetic random feasible LP {args.n}x{m}, {args.nnz_per_row} nnz/row "
+                               f"(density {args.nnz_per_row / args.n:.1e}), gen_lp recipe 'box' seed 0",
+                   "nnz": nnz, "step": f"{args.mode} PDHG iteration incl. 3 KKT evaluations per 40 iterations and restarts",
+                   "primal_weight_update": True, "restarts_in_timed_region": None,
+                   "parallelism": "single GPU" if world == 1 else f"row-block shards of K and K' over {world} GPUs, "
+                                                                  f"all-gather(xbar), all-gather(y) per iteration (RCCL)"},
+        "roofline": roofline,
+        "setup_s": round(setup_s, 1),
+    }
+    out["config"]["restarts_in_timed_region"] = drv.n
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        del drv, eng
+        torch.cuda.empty_cache()
+        out["cpu_baseline"] = cpu_baseline(args, dt)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.dist.barrier()
+        comm.dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -56,115 +56,162 @@ def _global_norm(v_local: torch.Tensor, comm: Optional[Comm]) -> float:
     return float(torch.sqrt(s))
 
 
+class PdhgDriver:
+    """The reference's two nested loops (pdhg.py:54-177) as a resumable state machine over an engine.
+
+    ``advance(max_iters)`` runs PDHG iterations up to the next restart check (every
+    ``restart_period`` iterations since the last restart), performs the check, and on a restart does the
+    post-restart work (primal weight, KKT_first, termination test).  ``run_pdlp`` loops over it; the
+    benchmark times the very same calls.
+    """
+
+    def __init__(self, eng: PdlpEngine, restart_period=40, primal_update=False, adaptive=False, precondition=False,
+                 tol=1e-4, verbose=False, trace=None):
+        self.eng, self.period = eng, int(restart_period)
+        self.primal_update, self.adaptive, self.precondition = bool(primal_update), bool(adaptive), bool(precondition)
+        self.tol, self.verbose, self.trace = tol, verbose, trace
+        self.t = _np_t(eng.dtype)
+        self.q_norm = self.t(_global_norm(eng.q, eng.comm))                 # pdhg.py:19-20
+        self.c_norm = self.t(_global_norm(eng.c, eng.comm))
+        self.beta = (0.2, 0.8, 0.36)                                        # pdhg.py:28
+        self.n = self.k = self.j = self.tt = 0
+        self.KKT_first = self.t(0)                                          # pdhg.py:48
+        self.omega = self.t(1)
+        self.res = None
+        self.solved = False
+
+    def start(self, sigma, x_init=None, y_init=None, theta=1.0):
+        t, eng = self.t, self.eng
+        eta = t(0.9) / t(sigma)                                             # pdhg.py:22
+        q_norm, c_norm = self.q_norm, self.c_norm
+        self.omega = (c_norm / q_norm) if (q_norm > 1e-6 and c_norm > 1e-6) else t(1.0)   # pdhg.py:23
+        zeros = lambda ln: torch.zeros(ln, dtype=eng.dtype, device=eng.device)
+        if x_init is not None and y_init is not None:                       # pdhg.py:31-36
+            eng.set_iterate(x_init, y_init)
+        else:
+            eng.set_iterate(zeros(eng.nl), zeros(eng.ml))
+        eng.set_step(eta, self.omega, theta, 0)
+        self.n = self.k = self.j = self.tt = 0
+        self.KKT_first = t(0)
+        self.res, self.solved = None, False
+
+    def advance(self, max_iters: int) -> int:
+        """Iterate up to the next restart check (at most ``max_iters``); returns the iterations done."""
+        eng, t = self.eng, self.t
+        iters = min(self.period - self.tt % self.period, int(max_iters))
+        if iters <= 0:
+            return 0
+        eng.iterate(iters, self.adaptive)                                   # pdhg.py:76-112
+        self.k += iters
+        self.j += iters
+        self.tt += iters
+        if self.tt % self.period != 0:                                      # pdhg.py:115
+            return iters
+        if self.adaptive:
+            eng.flush_average()
+        eng.compute_average()                                               # pdhg.py:118-119
+        r_cur = eng.kkt(N.CUR, self.omega)                                  # pdhg.py:122-125
+        r_avg = eng.kkt(N.AVG, self.omega)
+        r_prev = eng.kkt(N.PREV, self.omega)
+        k_cur, k_avg, k_prev = t(r_cur["kkt"]), t(r_avg["kkt"]), t(r_prev["kkt"])
+        k_min = min(k_cur, k_avg)
+        self.j += 3                                                         # pdhg.py:128
+        if self.trace is not None:
+            self.trace["kkt"] += [float(k_cur), float(k_avg), float(k_prev)]
+        use_avg = bool(k_cur >= k_avg)
+        crit = -1
+        if k_min <= t(self.beta[0]) * self.KKT_first:                       # sufficient, pdhg.py:131
+            crit = 0
+        elif k_min <= t(self.beta[1]) * self.KKT_first and k_min > k_prev:  # necessary, pdhg.py:135
+            crit = 1
+        elif self.tt >= self.beta[2] * self.k:                              # artificial, pdhg.py:139
+            crit = 2
+        if crit >= 0:
+            if self.verbose:
+                print(f"{('Sufficient', 'Necessary', 'Artificial')[crit]} restart at iteration {self.tt} using the",
+                      "Average iterate." if use_avg else "Current iterate.")
+            if self.trace is not None:
+                self.trace["restarts"].append((crit, self.tt, int(use_avg)))
+            eng.restart(N.AVG if use_avg else N.CUR)
+            self.after_restart(r_avg if use_avg else r_cur)
+        return iters
+
+    def after_restart(self, chosen=None):
+        """pdhg.py:148-177: n += 1, primal weight, KKT_first, residuals, termination test."""
+        eng, t = self.eng, self.t
+        self.n += 1
+        self.tt = 0
+        if chosen is None:       # the KKT-pass cap ended the inner loop: continue from the current iterate
+            eng.restart(N.CUR)
+        if self.primal_update:                                              # pdhg.py:150-151
+            dx2, dy2 = eng.restart_distance()
+            self.omega = primal_weight_from_distances(dx2, dy2, self.omega, 0.5, t)
+            eng.set_omega(self.omega)
+            if self.trace is not None:
+                self.trace["omega"].append(float(self.omega))
+        eng.mark_restart_point()                                            # pdhg.py:63-64 of the next round
+        if chosen is None:
+            chosen = eng.kkt(N.CUR, self.omega)
+        # KKT_first at the restart point with the (new) omega: the residuals do not depend on omega, so
+        # the pass the reference repeats here (pdhg.py:153) is a re-weighting of numbers already known
+        self.KKT_first = kkt_from_residuals(chosen, self.omega, t)
+        self.j += 1                                                         # pdhg.py:154
+        if self.trace is not None:
+            self.trace["kkt"].append(float(self.KKT_first))
+        res = eng.kkt(N.CUR, self.omega, unscaled=True) if self.precondition else chosen   # pdhg.py:157-163
+        self.res = res
+        self.j += 1                                                         # pdhg.py:165
+        if self.verbose:
+            print(f"[{self.k}] Primal Obj: {res['p']:.4f}, Adjusted Dual Obj: {res['d_adj']:.4f}, "
+                  f"Gap: {res['gap'] / (1 + abs(res['p']) + abs(res['d_adj'])):.2e}, "
+                  f"Prim Res: {res['pr'] / (1 + self.q_norm):.2e}, Dual Res: {res['dr'] / (1 + self.c_norm):.2e}\n")
+        self.solved = check_termination(t(res["pr"]), t(res["dr"]), t(res["gap"]), t(res["p"]), t(res["d_adj"]),
+                                        self.q_norm, self.c_norm, t(self.tol))
+
+
+def estimate_sigma(eng: PdlpEngine, b0=None, power_iters=100, seed=None) -> float:
+    """spectral_norm_estimate_torch (helpers.py:41-51); the reference's start vector is an unseeded
+    torch.randn (quirk Q6) -- here ``b0`` or ``seed`` pins it, and every rank uses the same vector."""
+    if b0 is None:
+        g = torch.Generator().manual_seed(int(seed) if seed is not None else int(time.time_ns() % (2 ** 31)))
+        b0 = torch.randn(eng.n, generator=g, dtype=torch.float32).to(eng.device)
+        if eng.comm is not None:
+            eng.comm.dist.broadcast(b0, 0, group=eng.comm.group)
+    return eng.power_iteration(b0, power_iters)
+
+
 def run_pdlp(eng: PdlpEngine, max_kkt=100_000, tol=1e-4, verbose=True, restart_period=40, precondition=False,
              primal_update=False, adaptive=False, time_limit=3600, time_used=0, x_init=None, y_init=None,
              b0=None, sigma=None, power_iters=100, seed=None, trace=None):
     """The outer loop over an existing engine.  Returns (x_local, prim_obj, k, n, j, status, total_time)."""
     t0 = time.time()
-    t = _np_t(eng.dtype)
-    comm = eng.comm
-    q_norm = t(_global_norm(eng.q, comm))                                   # pdhg.py:19-20
-    c_norm = t(_global_norm(eng.c, comm))
+    drv = PdhgDriver(eng, restart_period, primal_update, adaptive, precondition, tol, verbose, trace)
     if sigma is None:                                                       # pdhg.py:22
-        if b0 is None:      # the reference draws an unseeded torch.randn (quirk Q6); same on every rank here
-            g = torch.Generator().manual_seed(int(seed) if seed is not None else int(time.time_ns() % (2 ** 31)))
-            b0 = torch.randn(eng.n, generator=g, dtype=torch.float32)
-            if comm is not None:
-                b0 = b0.to(eng.device)
-                comm.dist.broadcast(b0, 0, group=comm.group)
-        sigma = eng.power_iteration(b0, power_iters)
-    eta = t(0.9) / t(sigma)
-    omega = (c_norm / q_norm) if (q_norm > 1e-6 and c_norm > 1e-6) else t(1.0)   # pdhg.py:23
-    theta = 1.0
-    beta = (0.2, 0.8, 0.36)                                                 # pdhg.py:28
-    zeros = lambda ln: torch.zeros(ln, dtype=eng.dtype, device=eng.device)
-    if x_init is not None and y_init is not None:                           # pdhg.py:31-36
-        eng.set_iterate(x_init, y_init)
-    else:
-        eng.set_iterate(zeros(eng.nl), zeros(eng.ml))
-    eng.set_step(eta, omega, theta, 0)
-    n = k = j = 0
-    KKT_first = t(0)                                                        # pdhg.py:48
+        sigma = estimate_sigma(eng, b0, power_iters, seed)
+    drv.start(sigma, x_init, y_init)
     status = STATUS_KKT_LIMIT
-    res = None
-    while j < max_kkt:                                                      # pdhg.py:54
-        tt = 0
-        chosen = None
-        while j < max_kkt:                                                  # pdhg.py:67
+    while drv.j < max_kkt:                                                  # pdhg.py:54
+        n_before = drv.n
+        while drv.j < max_kkt and drv.n == n_before:                        # pdhg.py:67
             if time.time() - t0 + time_used >= time_limit:                  # pdhg.py:68-74 (checked per block)
                 status = STATUS_TIME_LIMIT
                 if verbose:
                     print("Time limit exceeded")
                 break
-            iters = min(restart_period - tt % restart_period, max_kkt - j)
-            eng.iterate(iters, adaptive)                                    # pdhg.py:76-112
-            k += iters
-            j += iters
-            tt += iters
-            if tt % restart_period == 0:                                    # pdhg.py:115
-                if adaptive:
-                    eng.flush_average()
-                eng.compute_average()                                       # pdhg.py:118-119
-                r_cur = eng.kkt(N.CUR, omega)                               # pdhg.py:122-125
-                r_avg = eng.kkt(N.AVG, omega)
-                r_prev = eng.kkt(N.PREV, omega)
-                k_cur, k_avg, k_prev = t(r_cur["kkt"]), t(r_avg["kkt"]), t(r_prev["kkt"])
-                k_min = min(k_cur, k_avg)
-                j += 3                                                      # pdhg.py:128
-                if trace is not None:
-                    trace["kkt"] += [float(k_cur), float(k_avg), float(k_prev)]
-                use_avg = bool(k_cur >= k_avg)
-                crit = -1
-                if k_min <= t(beta[0]) * KKT_first:                         # sufficient, pdhg.py:131
-                    crit = 0
-                elif k_min <= t(beta[1]) * KKT_first and k_min > k_prev:    # necessary, pdhg.py:135
-                    crit = 1
-                elif tt >= beta[2] * k:                                     # artificial, pdhg.py:139
-                    crit = 2
-                if crit >= 0:
-                    if verbose:
-                        print(f"{('Sufficient', 'Necessary', 'Artificial')[crit]} restart at iteration {tt} using the",
-                              "Average iterate." if use_avg else "Current iterate.")
-                    if trace is not None:
-                        trace["restarts"].append((crit, tt, int(use_avg)))
-                    eng.restart(N.AVG if use_avg else N.CUR)
-                    chosen = r_avg if use_avg else r_cur
-                    break
+            drv.advance(max_kkt - drv.j)
         if status == STATUS_TIME_LIMIT:
             break
-        n += 1
-        if chosen is None:       # the KKT-pass cap ended the inner loop: continue from the current iterate
-            eng.restart(N.CUR)
-        if primal_update:                                                   # pdhg.py:150-151
-            dx2, dy2 = eng.restart_distance()
-            omega = primal_weight_from_distances(dx2, dy2, omega, 0.5, t)
-            eng.set_omega(omega)
-            if trace is not None:
-                trace["omega"].append(float(omega))
-        eng.mark_restart_point()                                            # pdhg.py:63-64 of the next round
-        if chosen is None:
-            chosen = eng.kkt(N.CUR, omega)
-        # KKT_first at the restart point with the (new) omega: the residuals do not depend on omega, so
-        # the pass the reference repeats here (pdhg.py:153) is a re-weighting of numbers already known
-        KKT_first = kkt_from_residuals(chosen, omega, t)
-        j += 1                                                              # pdhg.py:154
-        if trace is not None:
-            trace["kkt"].append(float(KKT_first))
-        res = eng.kkt(N.CUR, omega, unscaled=True) if precondition else chosen   # pdhg.py:157-163
-        j += 1                                                              # pdhg.py:165
-        if verbose:
-            print(f"[{k}] Primal Obj: {res['p']:.4f}, Adjusted Dual Obj: {res['d_adj']:.4f}, "
-                  f"Gap: {res['gap'] / (1 + abs(res['p']) + abs(res['d_adj'])):.2e}, "
-                  f"Prim Res: {res['pr'] / (1 + q_norm):.2e}, Dual Res: {res['dr'] / (1 + c_norm):.2e}\n")
-        if check_termination(t(res["pr"]), t(res["dr"]), t(res["gap"]), t(res["p"]), t(res["d_adj"]), q_norm, c_norm, t(tol)):
+        if drv.n == n_before:        # left the inner loop through the KKT-pass cap (pdhg.py:67 -> :148)
+            drv.after_restart(None)
+        if drv.solved:                                                      # pdhg.py:173-177
             status = STATUS_SOLVED
             if verbose:
-                print(f"Converged at iteration {k} restart loop {n}")
+                print(f"Converged at iteration {drv.k} restart loop {drv.n}")
             break
     x_local, _ = eng.get_iterate(N.CUR)
     eng.synchronize()                                  # the reference reads its clock without a sync (Q10)
-    prim_obj = float(res["p"]) if res is not None else float("nan")
-    return x_local, prim_obj, k, n, j, status, time.time() - t0 + time_used
+    prim_obj = float(drv.res["p"]) if drv.res is not None else float("nan")
+    return x_local, prim_obj, drv.k, drv.n, drv.j, status, time.time() - t0 + time_used
 
 
 def pdlp_algorithm(K, m_ineq, c, q, l, u, device=None, max_kkt=100_000, tol=1e-4, verbose=True, restart_period=40,
