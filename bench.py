@@ -73,6 +73,18 @@ def time_kernel(eng, fn, reps):
     return sum(a.elapsed_time(b) for a, b in evs) / reps
 
 
+def host_cores() -> int:
+    """CPU cores this process may really use: cgroup quota, then affinity, then the machine's count."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("PDLP_CPU_THREADS", "16"))))   # a 1-GPU box shares its host: 16 cores
+
+
 def cpu_baseline(args, sv_dtype):
     """The CPU oracle (oracle/, a C restatement of the reference pinned by tests/golden) timed on the host
     cores of this box on a bounded sample: the same generator with fewer rows/columns and the same
@@ -86,7 +98,7 @@ def cpu_baseline(args, sv_dtype):
     o = orc.OracleLP(lp.m, lp.n, lp.m_ineq, h(K.rowptr), h(K.colidx), h(K.val), h(lp.c), h(lp.q), h(lp.l), h(lp.u),
                      dtype=np.float32 if sv_dtype == torch.float32 else np.float64,
                      trans=(h(K.t_rowptr), h(K.t_colidx), h(K.t_val)))
-    cores = orc.set_threads(os.cpu_count() or 1)
+    cores = orc.set_threads(host_cores())
     x, y = np.zeros(lp.n, o.dtype), np.zeros(lp.m, o.dtype)
     eta, om = o.dtype.type(0.01), o.dtype.type(1.0)
     adaptive = args.mode == "adaptive"
