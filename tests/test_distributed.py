@@ -1,0 +1,170 @@
+"""Multi-rank path: row-block shards of K and K', all-gather of xbar / y between the half-steps.
+
+CPU (gloo, world size 2): the sharding + padding + exchange logic, with the ORACLE's SpMV standing in
+for the local kernels (the HIP kernels need a GPU) -- the result must equal the unsharded oracle step.
+GPU (marked): two ranks share the one MI355X of the test box, collectives over gloo; whole solves must
+match the single-rank engine.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from torchpdlp_amd.distributed import block, padded, shard_arrays
+from torchpdlp_amd.sparse import CsrPair
+from torchpdlp_amd.synthetic import gen_lp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _init(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _lp(device="cpu"):
+    # sizes that do NOT divide by the world size: exercises the padding
+    lp = gen_lp(301, 403, 4, seed=21, recipe="mixed", ineq_frac=0.6, device=device)
+    return lp, CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
+
+
+def _cpu_worker(rank, world, port, ret):
+    from oracle import oracle as orc          # checker only
+    from torchpdlp_amd.engine import Comm
+    _init(rank, world, port)
+    try:
+        orc.set_threads(1)
+        comm = Comm()
+        lp, K = _lp()
+        sh = shard_arrays(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq, rank, world)
+        (r0, r1), (c0, c1) = sh["rows"], sh["cols"]
+        mp_, np_ = sh["m"], sh["n"]
+        z = np.zeros
+        # local operators through the oracle's CSR product (global column indices, padded widths)
+        Kr = orc.OracleLP(r1 - r0, np_, 0, *(t.numpy() for t in sh["K_rows"]), z(np_), z(r1 - r0), z(np_), z(np_),
+                          trans=(z(np_ + 1, np.int32), z(0, np.int32), z(0, np.float32)))
+        KTr = orc.OracleLP(c1 - c0, mp_, 0, *(t.numpy() for t in sh["KT_rows"]), z(mp_), z(c1 - c0), z(mp_), z(mp_),
+                           trans=(z(mp_ + 1, np.int32), z(0, np.int32), z(0, np.float32)))
+        g = torch.Generator().manual_seed(3)
+        x = torch.zeros(np_); x[:lp.n] = torch.minimum(torch.maximum(torch.randn(lp.n, generator=g), lp.l), lp.u)
+        y = torch.zeros(mp_); y[:lp.m] = torch.randn(lp.m, generator=g); y[:lp.m_ineq].clamp_(min=0)
+        eta, omega = np.float32(0.07), np.float32(1.3)
+        tau, sigma = eta / omega, eta * omega
+        c, q, l, u = (sh[k].numpy() for k in ("c", "q", "l", "u"))
+        for _ in range(3):     # three fixed steps, sharded (step.py:25-38)
+            kty = KTr.spmv(y.numpy())                                   # this rank's block of K'y
+            xl = x[c0:c1].numpy()
+            xn = np.minimum(np.maximum(xl - tau * (c - kty), l), u)
+            xbar = torch.zeros(np_); xbar[c0:c1] = torch.from_numpy(xn + 1.0 * (xn - xl))
+            comm.all_gather(xbar)                                       # every rank's block of xbar
+            kxb = Kr.spmv(xbar.numpy())
+            yl = y[r0:r1].numpy()
+            yn = yl + sigma * (q - kxb)
+            ineq_end = max(0, min(r1, lp.m_ineq) - r0)
+            yn[:ineq_end] = np.maximum(yn[:ineq_end], 0)
+            x = torch.zeros(np_); x[c0:c1] = torch.from_numpy(xn); comm.all_gather(x)
+            y = torch.zeros(mp_); y[r0:r1] = torch.from_numpy(yn); comm.all_gather(y)
+        # reference: the unsharded oracle
+        o = orc.OracleLP(lp.m, lp.n, lp.m_ineq, *(t.numpy() for t in (lp.rowptr, lp.colidx, lp.val, lp.c, lp.q, lp.l, lp.u)))
+        g = torch.Generator().manual_seed(3)
+        xo = torch.minimum(torch.maximum(torch.randn(lp.n, generator=g), lp.l), lp.u).numpy()
+        yo = torch.randn(lp.m, generator=g); yo[:lp.m_ineq].clamp_(min=0); yo = yo.numpy()
+        for _ in range(3):
+            xo, yo = o.step_fixed(xo, yo, eta, omega, 1.0)
+        np.testing.assert_allclose(x[:lp.n].numpy(), xo, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(y[:lp.m].numpy(), yo, rtol=1e-5, atol=1e-6)
+        assert float(x[lp.n:].abs().sum()) == 0 and float(y[lp.m:].abs().sum()) == 0     # padding stays at 0
+        # an 8-double all-reduce like the KKT partial sums
+        red = torch.tensor([float(rank + 1)] * 8, dtype=torch.float64)
+        comm.all_reduce_sum(red)
+        assert red.tolist() == [3.0] * 8
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_step_equals_unsharded_cpu_gloo():
+    world = 2
+    port = _free_port()
+    with mp.Manager() as man:
+        ret = man.dict()
+        mp.spawn(_cpu_worker, args=(world, port, ret), nprocs=world, join=True)
+        assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def test_block_partition_and_padding():
+    for v, w in ((403, 2), (301, 2), (10_000_000, 8), (7, 4), (8, 8)):
+        vp = padded(v, w)
+        assert vp % w == 0 and 0 <= vp - v < w
+        blocks = [block(vp, r, w) for r in range(w)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == vp
+        assert all(blocks[i][1] == blocks[i + 1][0] for i in range(w - 1))
+    lp, K = _lp()
+    parts = [shard_arrays(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq, r, 2) for r in range(2)]
+    assert sum(int(p["K_rows"][2].numel()) for p in parts) == K.nnz == sum(int(p["KT_rows"][2].numel()) for p in parts)
+    assert all(p["K_rows"][0].numel() == p["rows"][1] - p["rows"][0] + 1 for p in parts)
+    # the padding variables are fixed at zero and the padding rows are empty equalities
+    last = parts[-1]
+    npad = last["n"] - lp.n
+    assert npad == 1 and float(last["l"][-1]) == 0 == float(last["u"][-1]) == float(last["c"][-1])
+    assert int(last["K_rows"][0][-1]) == int(last["K_rows"][0][-2])      # empty last row
+    assert all(int(p["K_rows"][1].max()) < lp.n for p in parts)
+
+
+def _gpu_worker(rank, world, port, ret):
+    import torchpdlp_amd as tp
+    from torchpdlp_amd.distributed import gather_solution, shard_engine
+    from torchpdlp_amd.solver import run_pdlp
+    _init(rank, world, port)
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        lp, K = _lp(dev)
+        comm = tp.Comm()
+        b0 = torch.randn(padded(lp.n, world), generator=torch.Generator().manual_seed(9)).to(dev)
+        b0[lp.n:] = 0
+        out = {}
+        for adaptive in (False, True):
+            eng = shard_engine(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq, comm)
+            trace = dict(kkt=[], omega=[], restarts=[])
+            x, obj, k, n, j, status, _ = run_pdlp(eng, tol=1e-4, verbose=False, primal_update=True, adaptive=adaptive, b0=b0,
+                                                  trace=trace)
+            xf = gather_solution(eng, x, lp.n)
+            out[adaptive] = (xf.cpu(), obj, k, n, j, status, trace)
+            del eng
+        if rank == 0:      # the same solves on one rank
+            for adaptive in (False, True):
+                eng1 = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
+                tr1 = dict(kkt=[], omega=[], restarts=[])
+                x1, obj1, k1, n1, j1, st1, _ = run_pdlp(eng1, tol=1e-4, verbose=False, primal_update=True, adaptive=adaptive,
+                                                        b0=b0[:lp.n], trace=tr1)
+                xf, obj, k, n, j, status, trace = out[adaptive]
+                assert status == st1 == "Solved"
+                assert abs(obj - lp.opt_obj) <= 2e-3 * (1 + abs(lp.opt_obj))
+                assert abs(obj - obj1) <= 2e-3 * (1 + abs(obj1))
+                nk = 4 if adaptive else 10
+                np.testing.assert_allclose(trace["kkt"][:nk], tr1["kkt"][:nk], rtol=5e-2 if adaptive else 1e-3)
+                assert trace["restarts"][:1] == tr1["restarts"][:1]
+                assert j == k + (len(trace["kkt"]) - n) + 2 * n
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_match_single_rank():
+    world = 2
+    port = _free_port()
+    with mp.Manager() as man:
+        ret = man.dict()
+        mp.spawn(_gpu_worker, args=(world, port, ret), nprocs=world, join=True)
+        assert dict(ret) == {0: "ok", 1: "ok"}

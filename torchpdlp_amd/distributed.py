@@ -50,12 +50,9 @@ def _pad_vec(v: torch.Tensor, have: int, a: int, b: int, fill: float = 0.0) -> t
     return out
 
 
-def shard_engine(K: CsrPair, c, q, l, u, m_ineq: int, comm: Optional[Comm], d_col=None, d_row=None) -> PdlpEngine:
-    """Engine for this rank's block of a problem every rank holds in full (small/medium problems, tests,
-    and the benchmark, where every rank generates the same seeded instance and keeps only its block)."""
-    if comm is None or comm.world == 1:
-        return PdlpEngine.from_full(K, c, q, l, u, m_ineq, d_col=d_col, d_row=d_row)
-    W, r = comm.world, comm.rank
+def shard_arrays(K: CsrPair, c, q, l, u, m_ineq: int, rank: int, world: int, d_col=None, d_row=None) -> dict:
+    """This rank's blocks of a problem held in full: keyword arguments for ``PdlpEngine`` (minus ``comm``)."""
+    W, r = world, rank
     m, n = K.m, K.n
     mp, np_ = padded(m, W), padded(n, W)
     r0, r1 = block(mp, r, W)
@@ -67,10 +64,18 @@ def shard_engine(K: CsrPair, c, q, l, u, m_ineq: int, comm: Optional[Comm], d_co
     a, b = int(K.t_rowptr[min(c0, n)]), int(K.t_rowptr[min(c1, n)])
     KT_rows = (_pad_rowptr(K.t_rowptr, n, c0, c1), K.t_colidx[a:b].contiguous(), K.t_val[a:b].contiguous())
     opt = lambda v, have, lo, hi, fill: None if v is None else _pad_vec(vec(v, have), have, lo, hi, fill)
-    return PdlpEngine(mp, np_, m_ineq, K_rows, KT_rows,
-                      _pad_vec(vec(c, n), n, c0, c1), _pad_vec(vec(q, m), m, r0, r1),
-                      _pad_vec(vec(l, n), n, c0, c1), _pad_vec(vec(u, n), n, c0, c1),
-                      rows=(r0, r1), cols=(c0, c1), d_col=opt(d_col, n, c0, c1, 1.0), d_row=opt(d_row, m, r0, r1, 1.0), comm=comm)
+    return dict(m=mp, n=np_, m_ineq=m_ineq, K_rows=K_rows, KT_rows=KT_rows,
+                c=_pad_vec(vec(c, n), n, c0, c1), q=_pad_vec(vec(q, m), m, r0, r1),
+                l=_pad_vec(vec(l, n), n, c0, c1), u=_pad_vec(vec(u, n), n, c0, c1),
+                rows=(r0, r1), cols=(c0, c1), d_col=opt(d_col, n, c0, c1, 1.0), d_row=opt(d_row, m, r0, r1, 1.0))
+
+
+def shard_engine(K: CsrPair, c, q, l, u, m_ineq: int, comm: Optional[Comm], d_col=None, d_row=None) -> PdlpEngine:
+    """Engine for this rank's block of a problem every rank holds in full (small/medium problems, tests,
+    and the benchmark, where every rank generates the same seeded instance and keeps only its block)."""
+    if comm is None or comm.world == 1:
+        return PdlpEngine.from_full(K, c, q, l, u, m_ineq, d_col=d_col, d_row=d_row)
+    return PdlpEngine(comm=comm, **shard_arrays(K, c, q, l, u, m_ineq, comm.rank, comm.world, d_col, d_row))
 
 
 def gather_solution(eng: PdlpEngine, x_local: torch.Tensor, n_true: int) -> torch.Tensor:
