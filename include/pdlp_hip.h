@@ -73,6 +73,20 @@ typedef struct pdlp_problem {
     void* stream;               /* hipStream_t all work is enqueued on (0 = null stream)                    */
 } pdlp_problem;
 
+/* Optional panel-tiled copy of one of the two matrices (layout and builder: torchpdlp_amd/tiled.py).
+ * Rows are cut into blocks of 2^lrb (= 8192) rows, columns into panels of 2^lw entries; a tile is
+ * (row block, panel).  Items of a tile are sorted by column; item = value + ((slot << lw) | local column),
+ * slot = rank of the item in row order inside the tile; tiles are padded to multiples of 4 items with
+ * (value 0, slot = number of real items, column 0).  cnt holds one byte per (tile, row): the row's items. */
+typedef struct pdlp_tiles {
+    int32_t lw, lrb, cap;       /* cap: most items in any tile (<= 12288)                                  */
+    int32_t nblk, npanel;       /* row blocks, column panels                                               */
+    const uint32_t* idx;        /* [items]                                                                 */
+    const void* val;            /* [items]                                                                 */
+    const int32_t* tile_ptr;    /* [nblk*npanel + 1] item offsets, multiples of 4                          */
+    const uint8_t* cnt;         /* [nblk*npanel*8192]                                                      */
+} pdlp_tiles;
+
 typedef struct pdlp_solver* pdlp_handle;
 
 const char* pdlp_strerror(int code);
@@ -86,6 +100,10 @@ int pdlp_workspace_bytes(const pdlp_problem* p, int64_t* bytes);
  * host once) and carves the caller's workspace (256-byte aligned device memory).  x = y = 0. */
 int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_t workspace_bytes);
 void pdlp_destroy(pdlp_handle h);
+/* Use the panel-tiled copy for every product with K (transpose = 0) or K' (transpose = 1) from now on;
+ * NULL goes back to the CSR arrays.  The arrays must outlive the handle and be 16-byte aligned.
+ * Same results up to summation order; several times faster when the gathered vector exceeds the L2. */
+int pdlp_attach_tiles(pdlp_handle h, int transpose, const pdlp_tiles* t);
 /* device address of one of the PDLP_BUF_* buffers (inside the workspace) */
 int pdlp_buffer_ptr(pdlp_handle h, int which, void** ptr);
 

@@ -31,6 +31,12 @@ class PdlpProblem(C.Structure):
                 ("d_col", C.c_void_p), ("d_row", C.c_void_p), ("stream", C.c_void_p)]
 
 
+class PdlpTiles(C.Structure):
+    """mirror of ``struct pdlp_tiles``"""
+    _fields_ = [("lw", C.c_int32), ("lrb", C.c_int32), ("cap", C.c_int32), ("nblk", C.c_int32), ("npanel", C.c_int32),
+                ("idx", C.c_void_p), ("val", C.c_void_p), ("tile_ptr", C.c_void_p), ("cnt", C.c_void_p)]
+
+
 # every symbol include/pdlp_hip.h declares: name -> (restype, argtypes)
 _H = C.c_void_p
 _I, _I64, _D, _P = C.c_int, C.c_int64, C.c_double, C.c_void_p
@@ -40,6 +46,7 @@ SIGNATURES = {
     "pdlp_workspace_bytes": (_I, [C.POINTER(PdlpProblem), C.POINTER(_I64)]),
     "pdlp_create": (_I, [C.POINTER(_H), C.POINTER(PdlpProblem), _P, _I64]),
     "pdlp_destroy": (None, [_H]),
+    "pdlp_attach_tiles": (_I, [_H, _I, C.POINTER(PdlpTiles)]),
     "pdlp_buffer_ptr": (_I, [_H, _I, C.POINTER(_P)]),
     "pdlp_set_iterate": (_I, [_H, _P, _P]),
     "pdlp_get_iterate": (_I, [_H, _I, _P, _P]),

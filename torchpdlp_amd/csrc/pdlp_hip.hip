@@ -232,6 +232,120 @@ __global__ __launch_bounds__(BLOCK) void k_csr_fused(const int32_t* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// the panel-tiled kernel (format: torchpdlp_amd/tiled.py).  One workgroup of TNT threads owns TRB rows and
+// walks the column panels in order; per tile:
+//   pass 1  items are stored sorted by column: 16-byte streaming loads of (packed index, value), gathers
+//           from an L2-resident panel of the vector (lanes share lines), product stored to lds[slot]
+//           (slot = the item's rank in row order: a transposition through LDS, plain stores);
+//   pass 2  every thread owns 16 consecutive rows: it loads their 16 segment lengths (one 16-byte load),
+//           a workgroup scan gives its first slot, and it sums its segments into 16 register accumulators.
+// After the last panel the row sums go through LDS once more so that the epilogue runs with consecutive
+// lanes on consecutive rows (coalesced vector traffic).
+// ------------------------------------------------------------------------------------------------
+constexpr int TNT = 512;                 // threads per workgroup
+constexpr int TRPT = 16;                 // rows per thread
+constexpr int TRB = TNT * TRPT;          // 8192 rows per workgroup
+constexpr int TCAP = 12288;              // items per tile
+
+template <typename T> struct Vec4 { T x, y, z, w; };
+
+template <typename T, class Epi>
+__global__ __launch_bounds__(TNT) void k_tiled_fused(const uint32_t* __restrict__ tidx, const T* __restrict__ tval,
+                                                     const int32_t* __restrict__ tile_ptr, const uint8_t* __restrict__ tcnt,
+                                                     int npanel, int lw, int nrows, const T* __restrict__ vin, Epi epi,
+                                                     double* __restrict__ partials)
+{
+    __shared__ __attribute__((aligned(16))) T prod[TCAP + 8];
+    __shared__ int wsum[TNT / 64];
+    __shared__ double dred8[TNT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = blockIdx.x;
+    const uint32_t mask = (1u << lw) - 1u;
+    epi.load();
+    T acc[TRPT];
+#pragma unroll
+    for (int r = 0; r < TRPT; ++r) acc[r] = (T)0;
+
+    for (int p = 0; p < npanel; ++p) {
+        const size_t tile = (size_t)b * npanel + p;
+        const int i0 = tile_ptr[tile], i1 = tile_ptr[tile + 1];
+        const T* __restrict__ xin = vin + ((size_t)p << lw);
+        // segment lengths of this thread's 16 rows, and their exclusive offset in the workgroup
+        const uint4 cw = *reinterpret_cast<const uint4*>(tcnt + tile * TRB + (size_t)tid * TRPT);
+        int total;
+        {
+            // byte sums of 4 words: add the words' bytes pairwise (max 16*255 fits easily)
+            const uint32_t s01 = (cw.x & 0x00ff00ffu) + ((cw.x >> 8) & 0x00ff00ffu) + (cw.y & 0x00ff00ffu) + ((cw.y >> 8) & 0x00ff00ffu);
+            const uint32_t s23 = (cw.z & 0x00ff00ffu) + ((cw.z >> 8) & 0x00ff00ffu) + (cw.w & 0x00ff00ffu) + ((cw.w >> 8) & 0x00ff00ffu);
+            const uint32_t s = s01 + s23;
+            total = (int)((s & 0xffffu) + (s >> 16));
+        }
+        int incl = total;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        // pass 1
+        for (int i = i0 + tid * 4; i < i1; i += TNT * 4) {
+            const uint4 pk = *reinterpret_cast<const uint4*>(tidx + i);
+            const Vec4<T> v = *reinterpret_cast<const Vec4<T>*>(tval + i);
+            const T x0 = xin[pk.x & mask], x1 = xin[pk.y & mask], x2 = xin[pk.z & mask], x3 = xin[pk.w & mask];
+            prod[pk.x >> lw] = v.x * x0;
+            prod[pk.y >> lw] = v.y * x1;
+            prod[pk.z >> lw] = v.z * x2;
+            prod[pk.w >> lw] = v.w * x3;
+        }
+        __syncthreads();
+        int start = incl - total;
+#pragma unroll
+        for (int w = 0; w < TNT / 64; ++w) start += (w < wv) ? wsum[w] : 0;
+        // pass 2
+        const uint32_t words[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+        for (int r = 0; r < TRPT; ++r) {
+            const int c = (int)((words[r >> 2] >> ((r & 3) * 8)) & 0xffu);
+            T s = (T)0;
+            for (int k = 0; k < c; ++k) s += prod[start + k];
+            start += c;
+            acc[r] += s;
+        }
+        __syncthreads();
+    }
+    // row sums to LDS in row order (17-word stride per 16 rows against bank conflicts), then the epilogue
+#pragma unroll
+    for (int r = 0; r < TRPT; ++r) {
+        const int a = tid * TRPT + r;
+        prod[a + (a >> 4)] = acc[r];
+    }
+    __syncthreads();
+    double accd[NACC] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < TRPT; ++i) {
+        const int lrow = tid + i * TNT;
+        const int row = b * TRB + lrow;
+        if (row < nrows) epi(row, prod[lrow + (lrow >> 4)], accd);
+    }
+    if (Epi::NA > 0) {
+#pragma unroll
+        for (int r = 0; r < Epi::NA; ++r) {
+            double v = accd[r];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += shfl_xor_t(v, off);
+            __syncthreads();
+            if (lane == 0) dred8[wv] = v;
+            __syncthreads();
+            if (tid == 0) {
+                double t = 0.0;
+                for (int w = 0; w < TNT / 64; ++w) t += dred8[w];
+                partials[(size_t)b * NACC + r] = t;
+            }
+        }
+    }
+}
+
 // red[off + r] = sum over blocks of partials[b][r]   (one workgroup; fixed order => deterministic)
 __global__ __launch_bounds__(BLOCK) void k_finalize(const double* __restrict__ partials, int nblocks, int na,
                                                     double* __restrict__ red, int off)
@@ -469,6 +583,9 @@ struct Schedule {
     int32_t* blk = nullptr;   // device, nblk+1 row starts
     int nblk = 0;
     int grid = 0;
+    // panel-tiled copy (optional, attached by the caller): used instead of the CSR arrays when set
+    bool tiled = false;
+    pdlp_tiles t{};
 };
 
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
@@ -524,6 +641,12 @@ int launch_csr(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* 
 {
     const Schedule& s = transpose ? h->sKT : h->sK;
     if (s.nblk == 0) return PDLP_OK;
+    if (s.tiled) {
+        hipLaunchKernelGGL((k_tiled_fused<T, Epi>), dim3(s.t.nblk), dim3(TNT), 0, h->stream, s.t.idx, (const T*)s.t.val,
+                           s.t.tile_ptr, s.t.cnt, s.t.npanel, s.t.lw, (int)(transpose ? h->nl : h->ml), (const T*)vin, epi, partials);
+        HIP_TRY(hipGetLastError());
+        return PDLP_OK;
+    }
     const int32_t* rp = transpose ? h->p.KT_rowptr : h->p.K_rowptr;
     const int32_t* ci = transpose ? h->p.KT_colidx : h->p.K_colidx;
     const T* va = (const T*)(transpose ? h->p.KT_val : h->p.K_val);
@@ -532,6 +655,8 @@ int launch_csr(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* 
     HIP_TRY(hipGetLastError());
     return PDLP_OK;
 }
+
+inline int grid_of(const Schedule& s) { return s.nblk == 0 ? 0 : (s.tiled ? s.t.nblk : s.grid); }
 
 template <typename T> T* xloc(pdlp_handle h, int ix) { return (T*)h->xb[ix] + h->p.col0; }
 template <typename T> T* yloc(pdlp_handle h, int ix) { return (T*)h->yb[ix] + h->p.row0; }
@@ -542,7 +667,7 @@ template <typename T> int primal_half_t(pdlp_handle h, int adaptive)
     if (adaptive) {
         PrimalEpi<T, true> e{xloc<T>(h, h->ix_cur), xloc<T>(h, h->ix_prev), (T*)h->xbar + h->p.col0, (const T*)h->p.c,
                              (const T*)h->p.l, (const T*)h->p.u, (T*)h->x_sum, sc};
-        h->last_gridA = h->sKT.grid;
+        h->last_gridA = grid_of(h->sKT);
         return launch_csr<T>(h, true, h->yb[h->ix_cur], e, h->partA);
     }
     PrimalEpi<T, false> e{xloc<T>(h, h->ix_cur), xloc<T>(h, h->ix_prev), (T*)h->xbar + h->p.col0, (const T*)h->p.c,
@@ -565,7 +690,7 @@ template <typename T> int dual_half_t(pdlp_handle h, int adaptive)
         if (!h->kx_valid && (rc = refresh_kx_t<T>(h)) != PDLP_OK) return rc;
         DualEpi<T, true> e{yloc<T>(h, h->ix_cur), yloc<T>(h, h->ix_prev), (const T*)h->p.q, (T*)h->y_sum, (T*)h->kxb[0],
                            h->sc, h->ineq_end};
-        h->last_gridB = h->sK.grid;
+        h->last_gridB = grid_of(h->sK);
         rc = launch_csr<T>(h, false, h->xbar, e, h->partB);
     } else {
         DualEpi<T, false> e{yloc<T>(h, h->ix_cur), yloc<T>(h, h->ix_prev), (const T*)h->p.q, (T*)h->y_sum, (T*)h->kxb[0],
@@ -597,8 +722,8 @@ template <typename T> int kkt_local_t(pdlp_handle h, int which, int unscaled)
         KktPrimalEpi<T, false> ep{yloc<T>(h, ix), (const T*)h->p.q, nullptr, kx_out, h->ineq_end};
         if ((rc = launch_csr<T>(h, false, h->xb[ix], ep, h->partB)) != PDLP_OK) return rc;
     }
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partA, h->sKT.nblk ? h->sKT.grid : 0, 4, h->red, 0);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partB, h->sK.nblk ? h->sK.grid : 0, 2, h->red, 4);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partA, grid_of(h->sKT), 4, h->red, 0);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partB, grid_of(h->sK), 2, h->red, 4);
     HIP_TRY(hipGetLastError());
     if (which != PDLP_PREV) h->cand_valid[which == PDLP_CUR ? 0 : 1] = true;
     return PDLP_OK;
@@ -715,8 +840,9 @@ int64_t layout(const pdlp_problem* p, int64_t nnzK, int64_t nnzKT, int64_t* offs
     offs[k++] = c.take(nl * es);                                  // 9     x_last
     offs[k++] = c.take(ml * es);                                  // 10    y_last
     for (int i = 0; i < 3; ++i) offs[k++] = c.take(ml * es);     // 11..13 kx caches
-    offs[k++] = c.take((int64_t)MAX_GRID * NACC * 8);             // 14    partA
-    offs[k++] = c.take((int64_t)MAX_GRID * NACC * 8);             // 15    partB
+    const int64_t pgrid = MAX_GRID + (nl > ml ? nl : ml) / TRB + 1;  // CSR grid or one workgroup per 8192 rows (tiled)
+    offs[k++] = c.take(pgrid * NACC * 8);                         // 14    partA
+    offs[k++] = c.take(pgrid * NACC * 8);                         // 15    partB
     offs[k++] = c.take(PDLP_NRED * 8);                            // 16    red
     offs[k++] = c.take(PDLP_NSCAL * 8);                           // 17    sc
     offs[k++] = c.take((max_blocks(ml, nnzK) + 1) * 4);           // 18    schedule K
@@ -845,6 +971,21 @@ int pdlp_buffer_ptr(pdlp_handle h, int which, void** ptr)
         case PDLP_BUF_SCALARS: *ptr = h->sc; break;
         default: return PDLP_ERR_INVALID;
     }
+    return PDLP_OK;
+}
+
+int pdlp_attach_tiles(pdlp_handle h, int transpose, const pdlp_tiles* t)
+{
+    if (!h) return PDLP_ERR_INVALID;
+    Schedule& s = transpose ? h->sKT : h->sK;
+    if (!t) { s.tiled = false; return PDLP_OK; }
+    const int64_t rows = transpose ? h->nl : h->ml;
+    if (t->lrb != 13 || t->cap > TCAP || t->lw < 4 || t->lw > 20 || t->cap + 4 > (1 << (32 - t->lw))) return PDLP_ERR_INVALID;
+    if (t->nblk != (int)((rows + TRB - 1) / TRB) || t->npanel < 1) return PDLP_ERR_INVALID;
+    if (!t->idx || !t->val || !t->tile_ptr || !t->cnt) return PDLP_ERR_INVALID;
+    if (((uintptr_t)t->idx & 15u) || ((uintptr_t)t->val & 15u) || ((uintptr_t)t->cnt & 15u)) return PDLP_ERR_INVALID;
+    s.t = *t;
+    s.tiled = true;
     return PDLP_OK;
 }
 

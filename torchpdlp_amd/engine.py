@@ -7,12 +7,14 @@ over several GPUs, for the collectives between the half-steps (``torch.distribut
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
 
 from . import _native as N
 from .sparse import CsrPair, as_vec
+from . import tiled as _tiled
 
 _DT = {torch.float32: N.PDLP_F32, torch.float64: N.PDLP_F64}
 
@@ -96,6 +98,32 @@ class PdlpEngine:
         N.check(self.lib.pdlp_create(C.byref(self.h), C.byref(self.prob), self.workspace.data_ptr() + self._ws_off,
                                      nbytes.value), "pdlp_create")
         self._views = {}
+        self.tiles = [None, None]
+        self._maybe_attach_tiles()
+
+    # ---- panel-tiled matrix copies (fast path for wide gathered vectors) -------------------------------
+    def _maybe_attach_tiles(self):
+        """PDLP_TILED=0 never, =1 whenever the matrix is eligible, auto (default): when the vector a product
+        gathers from no longer fits the per-XCD L2 comfortably (>= 2^20 entries)."""
+        mode = os.environ.get("PDLP_TILED", "auto")
+        if mode == "0":
+            return
+        for transpose, (rp, ci, va), rows, cols in ((0, self.K, self.ml, self.n), (1, self.KT, self.nl, self.m)):
+            if rows == 0 or (mode != "1" and cols < (1 << 20)):
+                continue
+            t = _tiled.build_tiles(rp, ci, va, rows, cols)
+            if t is not None:
+                self.attach_tiles(transpose, t)
+
+    def attach_tiles(self, transpose: int, t: Optional["_tiled.Tiles"]):
+        if t is None:
+            N.check(self.lib.pdlp_attach_tiles(self.h, int(transpose), None), "pdlp_attach_tiles")
+            self.tiles[int(transpose)] = None
+            return
+        desc = N.PdlpTiles(t.lw, t.lrb, t.cap, t.nblk, t.npanel, t.idx.data_ptr(), t.val.data_ptr(), t.tile_ptr.data_ptr(),
+                           t.cnt.data_ptr())
+        N.check(self.lib.pdlp_attach_tiles(self.h, int(transpose), C.byref(desc)), "pdlp_attach_tiles")
+        self.tiles[int(transpose)] = t       # keep the arrays alive
 
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
