@@ -53,7 +53,13 @@ def _random_csr(m, n, lens, seed):
     rng = np.random.default_rng(seed)
     rp = np.zeros(m + 1, np.int32)
     rp[1:] = np.cumsum(lens)
-    ci = np.concatenate([np.sort(rng.choice(n, size=k, replace=False)) for k in lens]).astype(np.int32) if rp[-1] else np.zeros(0, np.int32)
+    if n > 100_000:      # (choice without replacement is O(n) per row)
+        rows = [np.unique(rng.integers(0, n, size=int(k))) for k in lens]
+        lens = np.array([len(r) for r in rows])
+        rp[1:] = np.cumsum(lens)
+        ci = np.concatenate(rows + [np.zeros(0, np.int64)]).astype(np.int32)
+    else:
+        ci = np.concatenate([np.sort(rng.choice(n, size=k, replace=False)) for k in lens]).astype(np.int32) if rp[-1] else np.zeros(0, np.int32)
     va = rng.standard_normal(rp[-1]).astype(np.float32)
     return rp, ci, va
 
@@ -424,8 +430,9 @@ def test_large_instance_properties():
 def test_tiled_spmv_matches_oracle(shape):
     from torchpdlp_amd.tiled import build_tiles
     rng = np.random.default_rng(11)
+    # eligibility: at most 12288 items per (8192 rows x 131072 columns) tile, for K and for K'
     if shape == "short":
-        m, n = 20000, 30000
+        m, n = 20000, 600000
         lens = rng.integers(1, 9, m)
     elif shape == "empty_rows":
         m, n = 9000, 500
@@ -433,13 +440,13 @@ def test_tiled_spmv_matches_oracle(shape):
         lens[:300] = 0
         lens[-7:] = 0
     elif shape == "ragged_ok":
-        m, n = 10000, 40000
+        m, n = 10000, 2_000_000
         lens = (rng.pareto(1.5, m) * 2).astype(np.int64).clip(0, 200)
     elif shape == "wide100":
-        m, n = 3000, 20000
+        m, n = 3000, 9_000_000
         lens = rng.integers(90, 111, m)
-    else:                                       # 3 row blocks x 4 panels
-        m, n = 20000, 400000
+    else:                                       # 3 row blocks x 5 panels
+        m, n = 20000, 600000
         lens = rng.integers(3, 8, m)
     rp, ci, va = _random_csr(m, n, lens, 5)
     z = np.zeros
@@ -460,7 +467,7 @@ def test_tiled_spmv_matches_oracle(shape):
 
 def test_tiled_engine_steps_and_kkt_match_csr_engine(monkeypatch):
     """the fused epilogues behind the tiled kernel: adaptive steps, averages and KKT vs the CSR path"""
-    lp = gen_lp(30000, 25000, 6, seed=4, device=DEV, recipe="mixed")
+    lp = gen_lp(300_000, 250_000, 3, seed=4, device=DEV, recipe="mixed")
     K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
     monkeypatch.setenv("PDLP_TILED", "0")
     e0 = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
