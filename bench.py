@@ -187,17 +187,18 @@ def main():
     ms_primal = time_kernel(eng, lambda: N.check(eng.lib.pdlp_primal_half(eng.h, a)), args.kernel_reps)
     # the dual kernel flips the iterate buffers each launch: harmless for timing
     ms_dual = time_kernel(eng, lambda: N.check(eng.lib.pdlp_dual_half(eng.h, a)), args.kernel_reps)
+    kfam = lambda t: "k_tiled_fused" if eng.tiles[t] is not None else "k_csr_fused"
     if ms_primal >= ms_dual:
-        kname, kms, kbytes = "k_csr_fused<PrimalEpi> (K'y + primal update)", ms_primal, b_primal
+        kname, kms, kbytes = f"{kfam(1)}<PrimalEpi> (K'y + primal update)", ms_primal, b_primal
     else:
-        kname, kms, kbytes = "k_csr_fused<DualEpi> (K xbar + dual update)", ms_dual, b_dual
+        kname, kms, kbytes = f"{kfam(0)}<DualEpi> (K xbar + dual update)", ms_dual, b_dual
     achieved = kbytes / (kms * 1e-3) / 1e9
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")       # rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, see profiles/README.md
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
-            key = f"n{args.n}_k{args.nnz_per_row}_{args.dtype}_{args.mode}_g{world}"
+            key = f"n{args.n}_k{args.nnz_per_row}_{args.dtype}_{args.mode}_g{world}_{kfam(1).split('_')[1]}"
             traffic = tj.get(key, {}).get("primal" if ms_primal >= ms_dual else "dual")
         except Exception:
             traffic = None

@@ -5,7 +5,7 @@ import pytest
 import scipy.sparse as sp
 import torch
 
-from torchpdlp_amd.tiled import build_tiles, emulate_spmv
+from torchpdlp_amd.tiled import NT, build_tiles, choose_rpt, emulate_spmv, tile_row_counts
 
 
 def _csr(m, n, lens, seed):
@@ -20,46 +20,58 @@ def _csr(m, n, lens, seed):
 @pytest.mark.parametrize("case", ["regular", "ragged_empty", "single_panel", "tall", "one_row"])
 def test_build_and_replay(case):
     rng = np.random.default_rng(1)
-    lw, lrb, cap = 6, 5, 200          # 64-column panels, 32-row blocks: many tiles even at test sizes
+    lw, rpt, cap = 6, 4, 1200         # 64-column panels, 2048-row blocks
     if case == "regular":
-        m, n, lens = 300, 1000, np.full(300, 7)
+        m, n, lens = 5000, 1000, np.full(5000, 7)
     elif case == "ragged_empty":
-        m, n = 257, 777
-        lens = rng.integers(0, 12, m)
+        m, n = 4100, 777
+        lens = rng.integers(0, 6, m)
         lens[:40] = 0
         lens[-3:] = 0
     elif case == "single_panel":
         m, n, lens = 100, 50, rng.integers(0, 5, 100)
     elif case == "tall":
-        m, n, lens = 2000, 130, rng.integers(1, 4, 2000)
+        m, n, lens = 7000, 130, rng.integers(0, 2, 7000)
     else:
         m, n, lens = 1, 500, np.array([9])
     rp, ci, va = _csr(m, n, lens, 2)
-    t = build_tiles(rp, ci, va, m, n, lw=lw, lrb=lrb, cap=cap, max_chunk_nnz=500)    # small chunks: several of them
+    t = build_tiles(rp, ci, va, m, n, lw=lw, rpt=rpt, cap=cap, max_chunk_nnz=9000)   # small chunks: several of them
     assert t is not None
-    RB, W = 1 << lrb, 1 << lw
+    RB, W = NT * rpt, 1 << lw
     assert t.nblk == (m + RB - 1) // RB and t.npanel == (n + W - 1) // W
     tp = t.tile_ptr.numpy()
-    assert tp[0] == 0 and np.all(np.diff(tp) >= 0) and np.all(tp % 4 == 0) and tp[-1] == t.items
-    assert int(t.cnt.long().sum()) == int(rp[-1])                      # every non-zero counted once
+    assert tp[0] == 0 and np.all(np.diff(tp) >= 0) and np.all(tp % 256 == 0) and tp[-1] == t.items
+    assert sum(int(tile_row_counts(t, k).sum()) for k in range(t.nblk * t.npanel)) == int(rp[-1])   # each non-zero once
     # items of a tile are sorted by column and their slots are a permutation of the row-order ranks
-    idx = t.idx.long().numpy() & 0xFFFFFFFF
+    # undo the 256-item interleave (physical 4*lane + j holds sorted 64*j + lane)
+    idx = (t.idx.long().numpy() & 0xFFFFFFFF).reshape(-1, 64, 4).transpose(0, 2, 1).reshape(-1)
+    val_sorted = t.val.numpy().reshape(-1, 64, 4).transpose(0, 2, 1).reshape(-1)
     for tile in range(t.nblk * t.npanel):
         seg = idx[tp[tile]:tp[tile + 1]]
-        real = int(t.cnt[tile * RB:(tile + 1) * RB].long().sum())
+        real = int(tile_row_counts(t, tile).sum())
         lcol, slot = seg & (W - 1), seg >> lw
         isreal = slot < real
         assert isreal.sum() == real and np.all(np.diff(lcol[isreal]) >= 0)
         assert sorted(slot[isreal].tolist()) == list(range(real))
-        assert np.all(t.val.numpy()[tp[tile]:tp[tile + 1]][~isreal] == 0)
+        assert np.all(val_sorted[tp[tile]:tp[tile + 1]][~isreal] == 0)
     x = torch.from_numpy(rng.standard_normal(n).astype(np.float32))
     ref = sp.csr_matrix((va.numpy().astype(np.float64), ci.numpy(), rp.numpy()), shape=(m, n)) @ x.numpy().astype(np.float64)
     np.testing.assert_allclose(emulate_spmv(t, x).numpy(), ref, rtol=1e-12, atol=1e-12)
 
 
 def test_not_eligible_when_a_tile_or_a_row_is_too_full():
-    rp, ci, va = _csr(64, 64, np.full(64, 40), 3)
-    assert build_tiles(rp, ci, va, 64, 64, lw=6, lrb=5, cap=200) is None         # 32 rows x 40 = 1280 items in one tile
-    assert build_tiles(rp, ci, va, 64, 64, lw=6, lrb=5, cap=2000) is not None
-    rp, ci, va = _csr(4, 600, np.array([300, 1, 1, 1]), 4)
-    assert build_tiles(rp, ci, va, 4, 600, lw=10, lrb=5, cap=2000) is None        # 256+ entries of one row in one panel
+    rp, ci, va = _csr(640, 64, np.full(640, 10), 3)
+    assert build_tiles(rp, ci, va, 640, 64, lw=6, rpt=2, cap=2000) is None        # 640 rows x 10 = 6400 items in one tile
+    assert build_tiles(rp, ci, va, 640, 64, lw=6, rpt=2, cap=8000) is not None
+    rp, ci, va = _csr(4, 600, np.array([30, 1, 1, 1]), 4)
+    assert build_tiles(rp, ci, va, 4, 600, lw=10, rpt=2, cap=2000) is None        # 16+ entries of one row in one panel
+    assert build_tiles(rp, ci, va.double(), 4, 600, lw=4, rpt=2) is None           # float32 only
+
+
+def test_choose_rpt_fills_whole_rounds():
+    # the bench matrix: 10M rows, 100 per row, 64K panels -> 0.655 items per (row, panel)
+    rpt = choose_rpt(10_000_000, 1_000_000_000, 10_000_000, 16)
+    nblk = -(-10_000_000 // (512 * rpt))
+    assert rpt % 2 == 0 and 512 * rpt * 0.6554 * 1.06 < 16384
+    assert nblk / (512 * -(-nblk // 512)) > 0.9
+    assert choose_rpt(1000, 3000, 1000, 16) >= 2

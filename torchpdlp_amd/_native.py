@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpdlp_hip.so")
+LIB_PATH = os.environ.get("PDLP_LIB", os.path.join(_HERE, "libpdlp_hip.so"))   # PDLP_LIB: profiling/ablation builds
 
 ABI_VERSION = 1
 PDLP_F32, PDLP_F64 = 0, 1
@@ -33,7 +33,7 @@ class PdlpProblem(C.Structure):
 
 class PdlpTiles(C.Structure):
     """mirror of ``struct pdlp_tiles``"""
-    _fields_ = [("lw", C.c_int32), ("lrb", C.c_int32), ("cap", C.c_int32), ("nblk", C.c_int32), ("npanel", C.c_int32),
+    _fields_ = [("lw", C.c_int32), ("rpt", C.c_int32), ("cap", C.c_int32), ("nblk", C.c_int32), ("npanel", C.c_int32),
                 ("idx", C.c_void_p), ("val", C.c_void_p), ("tile_ptr", C.c_void_p), ("cnt", C.c_void_p)]
 
 

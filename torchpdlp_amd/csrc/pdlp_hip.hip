@@ -233,53 +233,79 @@ __global__ __launch_bounds__(BLOCK) void k_csr_fused(const int32_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// the panel-tiled kernel (format: torchpdlp_amd/tiled.py).  One workgroup of TNT threads owns TRB rows and
-// walks the column panels in order; per tile:
-//   pass 1  items are stored sorted by column: 16-byte streaming loads of (packed index, value), gathers
-//           from an L2-resident panel of the vector (lanes share lines), product stored to lds[slot]
-//           (slot = the item's rank in row order: a transposition through LDS, plain stores);
-//   pass 2  every thread owns 16 consecutive rows: it loads their 16 segment lengths (one 16-byte load),
-//           a workgroup scan gives its first slot, and it sums its segments into 16 register accumulators.
-// After the last panel the row sums go through LDS once more so that the epilogue runs with consecutive
-// lanes on consecutive rows (coalesced vector traffic).
+// the panel-tiled kernel (format: torchpdlp_amd/tiled.py; float32 only).  A workgroup of 512 threads owns
+// 512*rpt rows and walks the column panels in order; two workgroups share a CU (64 KB of LDS each) and all
+// workgroups keep the same pace, so the 256 KB panel of the gathered vector stays in every XCD's L2.  Per tile:
+//   pass 1  items are stored sorted by column (interleaved so that one gather instruction covers 64 consecutive
+//           sorted items, i.e. few 128-byte lines): 16-byte streaming loads of (packed index, value) into
+//           registers one group (8192 items) ahead, gathers, product stored to lds[slot] (slot = the item's rank
+//           in row order: a transposition through LDS with plain stores, no atomics);
+//   pass 2  every thread owns rpt consecutive rows: their 4-bit segment lengths, a workgroup scan gives its
+//           first slot, and it sums its segments into register accumulators.  While one workgroup of the CU
+//           is in pass 2 the other one streams and gathers.
+// After the last panel the row sums go through LDS once more so that the epilogue runs with consecutive lanes
+// on consecutive rows (coalesced vector traffic).
 // ------------------------------------------------------------------------------------------------
 constexpr int TNT = 512;                 // threads per workgroup
-constexpr int TRPT = 16;                 // rows per thread
-constexpr int TRB = TNT * TRPT;          // 8192 rows per workgroup
-constexpr int TCAP = 12288;              // items per tile
+constexpr int TRPT_MAX = 40;             // most rows per thread
+constexpr int TCW = TRPT_MAX / 8;        // 32-bit words of 4-bit counts per thread and tile
+constexpr int TCAP = 16384;              // most items per tile
+constexpr int TU = 4;                    // 16-byte chunks per thread and register group
+constexpr int TGRP = TNT * 4 * TU;       // items per register group
 
-template <typename T> struct Vec4 { T x, y, z, w; };
+struct F4 { float x, y, z, w; };
 
-template <typename T, class Epi>
-__global__ __launch_bounds__(TNT) void k_tiled_fused(const uint32_t* __restrict__ tidx, const T* __restrict__ tval,
-                                                     const int32_t* __restrict__ tile_ptr, const uint8_t* __restrict__ tcnt,
-                                                     int npanel, int lw, int nrows, const T* __restrict__ vin, Epi epi,
-                                                     double* __restrict__ partials)
+template <class Epi>
+__global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restrict__ tidx, const float* __restrict__ tval,
+                                                        const int32_t* __restrict__ tile_ptr, const uint32_t* __restrict__ tcnt,
+                                                        int npanel, int lw, int rpt, int nrows, const float* __restrict__ vin,
+                                                        float* __restrict__ rowsum, Epi epi, double* __restrict__ partials)
 {
-    __shared__ __attribute__((aligned(16))) T prod[TCAP + 8];
+    __shared__ __attribute__((aligned(16))) float prod[TCAP + 8];
     __shared__ int wsum[TNT / 64];
     __shared__ double dred8[TNT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = blockIdx.x;
     const uint32_t mask = (1u << lw) - 1u;
     epi.load();
-    T acc[TRPT];
+    float acc[TRPT_MAX];
 #pragma unroll
-    for (int r = 0; r < TRPT; ++r) acc[r] = (T)0;
+    for (int r = 0; r < TRPT_MAX; ++r) acc[r] = 0.0f;
+
+    uint4 pk[TU];
+    F4 vv[TU];
+    const uint32_t trash = (uint32_t)TCAP << lw;       // slot TCAP (past every real slot), column 0
+    auto load_group = [&](int g0, int i1) {
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+            const int i = g0 + (u * TNT + tid) * 4;
+            if (i < i1) {
+                pk[u] = *reinterpret_cast<const uint4*>(tidx + i);
+                vv[u] = *reinterpret_cast<const F4*>(tval + i);
+            } else {
+                pk[u] = make_uint4(trash, trash, trash, trash);
+                vv[u] = F4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+        }
+    };
+    const size_t tile0 = (size_t)b * npanel;
+    int i0 = tile_ptr[tile0];
+    int i1 = tile_ptr[tile0 + 1];
+    load_group(i0, i1);
 
     for (int p = 0; p < npanel; ++p) {
-        const size_t tile = (size_t)b * npanel + p;
-        const int i0 = tile_ptr[tile], i1 = tile_ptr[tile + 1];
-        const T* __restrict__ xin = vin + ((size_t)p << lw);
-        // segment lengths of this thread's 16 rows, and their exclusive offset in the workgroup
-        const uint4 cw = *reinterpret_cast<const uint4*>(tcnt + tile * TRB + (size_t)tid * TRPT);
-        int total;
-        {
-            // byte sums of 4 words: add the words' bytes pairwise (max 16*255 fits easily)
-            const uint32_t s01 = (cw.x & 0x00ff00ffu) + ((cw.x >> 8) & 0x00ff00ffu) + (cw.y & 0x00ff00ffu) + ((cw.y >> 8) & 0x00ff00ffu);
-            const uint32_t s23 = (cw.z & 0x00ff00ffu) + ((cw.z >> 8) & 0x00ff00ffu) + (cw.w & 0x00ff00ffu) + ((cw.w >> 8) & 0x00ff00ffu);
-            const uint32_t s = s01 + s23;
-            total = (int)((s & 0xffffu) + (s >> 16));
+        const size_t tile = tile0 + p;
+        const float* __restrict__ xin = vin + ((size_t)p << lw);
+        const int i0n = i1, i1n = p + 1 < npanel ? tile_ptr[tile + 2] : i1;     // the next tile (empty after the last)
+        // segment lengths of this thread's rows (4 bits each) and their offset inside the wave
+        uint32_t cw[TCW];
+        const uint32_t* cp = tcnt + (tile * TNT + tid) * TCW;
+        int total = 0;
+#pragma unroll
+        for (int q = 0; q < TCW; ++q) {
+            cw[q] = cp[q];
+            const uint32_t n2 = (cw[q] & 0x0f0f0f0fu) + ((cw[q] >> 4) & 0x0f0f0f0fu);
+            total += (int)((n2 * 0x01010101u) >> 24);
         }
         int incl = total;
 #pragma unroll
@@ -288,45 +314,72 @@ __global__ __launch_bounds__(TNT) void k_tiled_fused(const uint32_t* __restrict_
             if (lane >= off) incl += o;
         }
         if (lane == 63) wsum[wv] = incl;
-        // pass 1
-        for (int i = i0 + tid * 4; i < i1; i += TNT * 4) {
-            const uint4 pk = *reinterpret_cast<const uint4*>(tidx + i);
-            const Vec4<T> v = *reinterpret_cast<const Vec4<T>*>(tval + i);
-            const T x0 = xin[pk.x & mask], x1 = xin[pk.y & mask], x2 = xin[pk.z & mask], x3 = xin[pk.w & mask];
-            prod[pk.x >> lw] = v.x * x0;
-            prod[pk.y >> lw] = v.y * x1;
-            prod[pk.z >> lw] = v.z * x2;
-            prod[pk.w >> lw] = v.w * x3;
+        // pass 1, one register group at a time; the next group (of this tile or of the next) is loaded as soon as
+        // the current one is consumed
+        for (int g0 = i0; g0 < i1; g0 += TGRP) {
+            float xg[TU * 4];
+#pragma unroll
+            for (int u = 0; u < TU; ++u) {
+#ifdef PDLP_ABL_NOGATHER
+                xg[4 * u + 0] = xg[4 * u + 1] = xg[4 * u + 2] = xg[4 * u + 3] = (float)(pk[u].x & 1u);
+#else
+                xg[4 * u + 0] = xin[pk[u].x & mask];
+                xg[4 * u + 1] = xin[pk[u].y & mask];
+                xg[4 * u + 2] = xin[pk[u].z & mask];
+                xg[4 * u + 3] = xin[pk[u].w & mask];
+#endif
+            }
+#pragma unroll
+            for (int u = 0; u < TU; ++u) {
+                prod[pk[u].x >> lw] = vv[u].x * xg[4 * u + 0];
+                prod[pk[u].y >> lw] = vv[u].y * xg[4 * u + 1];
+                prod[pk[u].z >> lw] = vv[u].z * xg[4 * u + 2];
+                prod[pk[u].w >> lw] = vv[u].w * xg[4 * u + 3];
+            }
+            if (g0 + TGRP < i1) load_group(g0 + TGRP, i1);
+            else load_group(i0n, i1n);
         }
+        if (i0 >= i1) load_group(i0n, i1n);              // (an empty tile consumed nothing)
         __syncthreads();
         int start = incl - total;
 #pragma unroll
         for (int w = 0; w < TNT / 64; ++w) start += (w < wv) ? wsum[w] : 0;
-        // pass 2
-        const uint32_t words[4] = {cw.x, cw.y, cw.z, cw.w};
+        // pass 2: segment sums of this thread's rows, in item order (measured: advancing four rows together or
+        // predicating the first items costs more LDS instructions than the per-row chains it saves)
+#ifndef PDLP_ABL_NOPASS2
 #pragma unroll
-        for (int r = 0; r < TRPT; ++r) {
-            const int c = (int)((words[r >> 2] >> ((r & 3) * 8)) & 0xffu);
-            T s = (T)0;
-            for (int k = 0; k < c; ++k) s += prod[start + k];
-            start += c;
-            acc[r] += s;
+        for (int r = 0; r < TRPT_MAX; ++r) {
+            if (r < rpt) {
+                const int c = (int)((cw[r >> 3] >> ((r & 7) * 4)) & 0xfu);
+                float s = 0.0f;
+                for (int k = 0; k < c; ++k) s += prod[start + k];
+                start += c;
+                acc[r] += s;
+            }
         }
+#else
+        acc[1] += (float)(start + (int)cw[0]);
+#endif
         __syncthreads();
+        i0 = i0n;
+        i1 = i1n;
     }
-    // row sums to LDS in row order (17-word stride per 16 rows against bank conflicts), then the epilogue
+    // The row sums sit in registers with thread t holding rows t*rpt .. t*rpt+rpt-1.  They go once through this
+    // workgroup's slice of a global scratch vector (written here, re-read below by the same workgroup: 8 bytes
+    // per row, L2 resident) so that the epilogue runs with consecutive lanes on consecutive rows and all of
+    // its vector traffic is coalesced.  (The 512*40 sums do not fit the 64 KB product buffer.)
+    const int rb = TNT * rpt;
+    float* __restrict__ rs = rowsum + (size_t)b * rb;
 #pragma unroll
-    for (int r = 0; r < TRPT; ++r) {
-        const int a = tid * TRPT + r;
-        prod[a + (a >> 4)] = acc[r];
-    }
+    for (int r = 0; r < TRPT_MAX; ++r)
+        if (r < rpt) rs[tid * rpt + r] = acc[r];
+    __threadfence_block();
     __syncthreads();
     double accd[NACC] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int i = 0; i < TRPT; ++i) {
+    for (int i = 0; i < rpt; ++i) {
         const int lrow = tid + i * TNT;
-        const int row = b * TRB + lrow;
-        if (row < nrows) epi(row, prod[lrow + (lrow >> 4)], accd);
+        const int row = b * rb + lrow;
+        if (row < nrows) epi(row, __builtin_nontemporal_load(rs + lrow), accd);
     }
     if (Epi::NA > 0) {
 #pragma unroll
@@ -631,6 +684,7 @@ struct pdlp_solver {
     char* kxb[3];                 // K x caches: [0] running, [1] from KKT(cur), [2] from KKT(avg)
     bool kx_valid, cand_valid[2];
     double *partA, *partB, *red, *sc;
+    float* rowsum;                // row sums of the tiled kernel on their way to the epilogue (rows + one row block)
     int last_gridA, last_gridB;   // grids of the last primal / dual launch (adaptive reduce)
 };
 
@@ -641,9 +695,10 @@ int launch_csr(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* 
 {
     const Schedule& s = transpose ? h->sKT : h->sK;
     if (s.nblk == 0) return PDLP_OK;
-    if (s.tiled) {
-        hipLaunchKernelGGL((k_tiled_fused<T, Epi>), dim3(s.t.nblk), dim3(TNT), 0, h->stream, s.t.idx, (const T*)s.t.val,
-                           s.t.tile_ptr, s.t.cnt, s.t.npanel, s.t.lw, (int)(transpose ? h->nl : h->ml), (const T*)vin, epi, partials);
+    if constexpr (sizeof(T) == 4) if (s.tiled) {
+        hipLaunchKernelGGL((k_tiled_fused<Epi>), dim3(s.t.nblk), dim3(TNT), 0, h->stream, s.t.idx, (const float*)s.t.val,
+                           s.t.tile_ptr, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, (int)(transpose ? h->nl : h->ml),
+                           (const float*)vin, h->rowsum, epi, partials);
         HIP_TRY(hipGetLastError());
         return PDLP_OK;
     }
@@ -840,13 +895,14 @@ int64_t layout(const pdlp_problem* p, int64_t nnzK, int64_t nnzKT, int64_t* offs
     offs[k++] = c.take(nl * es);                                  // 9     x_last
     offs[k++] = c.take(ml * es);                                  // 10    y_last
     for (int i = 0; i < 3; ++i) offs[k++] = c.take(ml * es);     // 11..13 kx caches
-    const int64_t pgrid = MAX_GRID + (nl > ml ? nl : ml) / TRB + 1;  // CSR grid or one workgroup per 8192 rows (tiled)
+    const int64_t pgrid = MAX_GRID + (nl > ml ? nl : ml) / (TNT * 2) + 1;  // CSR grid, or one workgroup per >= 2048 rows (tiled)
     offs[k++] = c.take(pgrid * NACC * 8);                         // 14    partA
     offs[k++] = c.take(pgrid * NACC * 8);                         // 15    partB
     offs[k++] = c.take(PDLP_NRED * 8);                            // 16    red
     offs[k++] = c.take(PDLP_NSCAL * 8);                           // 17    sc
     offs[k++] = c.take((max_blocks(ml, nnzK) + 1) * 4);           // 18    schedule K
     offs[k++] = c.take((max_blocks(nl, nnzKT) + 1) * 4);          // 19    schedule K'
+    offs[k++] = c.take(((nl > ml ? nl : ml) + (int64_t)TNT * TRPT_MAX) * 4);   // 20  rowsum scratch (tiled kernel)
     return c.off;
 }
 
@@ -925,6 +981,7 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     h->partA = (double*)(w + offs[14]); h->partB = (double*)(w + offs[15]);
     h->red = (double*)(w + offs[16]); h->sc = (double*)(w + offs[17]);
     h->sK.blk = (int32_t*)(w + offs[18]); h->sKT.blk = (int32_t*)(w + offs[19]);
+    h->rowsum = (float*)(w + offs[20]);
     h->kx_valid = false; h->cand_valid[0] = h->cand_valid[1] = false;
     h->last_gridA = h->last_gridB = 0;
 
@@ -979,11 +1036,13 @@ int pdlp_attach_tiles(pdlp_handle h, int transpose, const pdlp_tiles* t)
     if (!h) return PDLP_ERR_INVALID;
     Schedule& s = transpose ? h->sKT : h->sK;
     if (!t) { s.tiled = false; return PDLP_OK; }
+    if (h->p.dtype != PDLP_F32) return PDLP_ERR_INVALID;          // the tiled kernel is float32 only
     const int64_t rows = transpose ? h->nl : h->ml;
-    if (t->lrb != 13 || t->cap > TCAP || t->lw < 4 || t->lw > 20 || t->cap + 4 > (1 << (32 - t->lw))) return PDLP_ERR_INVALID;
-    if (t->nblk != (int)((rows + TRB - 1) / TRB) || t->npanel < 1) return PDLP_ERR_INVALID;
+    if (t->rpt < 2 || t->rpt > TRPT_MAX || (t->rpt & 1) || t->cap > TCAP || t->lw < 4 || t->lw > 16) return PDLP_ERR_INVALID;
+    const int64_t rb = (int64_t)TNT * t->rpt;
+    if (t->nblk != (int)((rows + rb - 1) / rb) || t->npanel < 1) return PDLP_ERR_INVALID;
     if (!t->idx || !t->val || !t->tile_ptr || !t->cnt) return PDLP_ERR_INVALID;
-    if (((uintptr_t)t->idx & 15u) || ((uintptr_t)t->val & 15u) || ((uintptr_t)t->cnt & 15u)) return PDLP_ERR_INVALID;
+    if (((uintptr_t)t->idx & 15u) || ((uintptr_t)t->val & 15u) || ((uintptr_t)t->cnt & 3u)) return PDLP_ERR_INVALID;
     s.t = *t;
     s.tiled = true;
     return PDLP_OK;

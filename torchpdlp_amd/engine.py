@@ -103,24 +103,45 @@ class PdlpEngine:
 
     # ---- panel-tiled matrix copies (fast path for wide gathered vectors) -------------------------------
     def _maybe_attach_tiles(self):
-        """PDLP_TILED=0 never, =1 whenever the matrix is eligible, auto (default): when the vector a product
-        gathers from no longer fits the per-XCD L2 comfortably (>= 2^20 entries)."""
+        """PDLP_TILED=0 never, =1 whenever the matrix is eligible, auto (default): for products whose gathered
+        vector has >= 2^20 entries (no longer comfortably L2 resident) build the tiles, time both kernels on
+        this device and keep the faster one."""
         mode = os.environ.get("PDLP_TILED", "auto")
         if mode == "0":
             return
         for transpose, (rp, ci, va), rows, cols in ((0, self.K, self.ml, self.n), (1, self.KT, self.nl, self.m)):
-            if rows == 0 or (mode != "1" and cols < (1 << 20)):
+            if rows == 0 or self.dtype != torch.float32 or (mode != "1" and cols < (1 << 20)):
                 continue
             t = _tiled.build_tiles(rp, ci, va, rows, cols)
-            if t is not None:
+            if t is None:
+                continue
+            if mode == "1":
                 self.attach_tiles(transpose, t)
+                continue
+            vin = torch.zeros(cols, dtype=self.dtype, device=self.device)
+            out = torch.empty(rows, dtype=self.dtype, device=self.device)
+            t_csr = self._time_spmv(transpose, vin, out)
+            self.attach_tiles(transpose, t)
+            if self._time_spmv(transpose, vin, out) >= t_csr:
+                self.attach_tiles(transpose, None)
+
+    def _time_spmv(self, transpose: int, vin: torch.Tensor, out: torch.Tensor, reps: int = 3) -> float:
+        call = lambda: N.check(self.lib.pdlp_spmv(self.h, int(transpose), vin.data_ptr(), out.data_ptr()), "pdlp_spmv")
+        call()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(self.stream)
+        for _ in range(reps):
+            call()
+        b.record(self.stream)
+        b.synchronize()
+        return a.elapsed_time(b) / reps
 
     def attach_tiles(self, transpose: int, t: Optional["_tiled.Tiles"]):
         if t is None:
             N.check(self.lib.pdlp_attach_tiles(self.h, int(transpose), None), "pdlp_attach_tiles")
             self.tiles[int(transpose)] = None
             return
-        desc = N.PdlpTiles(t.lw, t.lrb, t.cap, t.nblk, t.npanel, t.idx.data_ptr(), t.val.data_ptr(), t.tile_ptr.data_ptr(),
+        desc = N.PdlpTiles(t.lw, t.rpt, t.cap, t.nblk, t.npanel, t.idx.data_ptr(), t.val.data_ptr(), t.tile_ptr.data_ptr(),
                            t.cnt.data_ptr())
         N.check(self.lib.pdlp_attach_tiles(self.h, int(transpose), C.byref(desc)), "pdlp_attach_tiles")
         self.tiles[int(transpose)] = t       # keep the arrays alive

@@ -5,20 +5,25 @@ lives in the Infinity Cache and every 4-byte gather costs a 128-byte line fill -
 moves 15x its algorithmic bytes.  Gathers run at the streaming rate only when (a) the gathered window is
 L2 resident and (b) consecutive lanes share cache lines.  So:
 
-* columns are cut into panels of ``W = 2**lw`` entries (512 KB of f32 for lw = 17), rows into blocks of
-  ``RB = 2**lrb`` rows (one workgroup each); a *tile* is (row block, panel);
+* columns are cut into panels of ``W = 2**lw`` entries (256 KB of f32 for lw = 16), rows into blocks of
+  ``RB = 512*rpt`` rows (one 512-thread workgroup each, ``rpt`` rows per thread); a *tile* is (row block, panel);
 * inside a tile the non-zeros are stored sorted by COLUMN, so a wave's 64 gathers touch a handful of
   lines of an L2-resident panel; all workgroups walk the panels in the same order at the same pace;
 * each item carries ``slot``, its rank in ROW order inside the tile: the product is written to
   ``lds[slot]`` (a transposition through LDS, plain stores, no atomics), after which every thread reduces
-  the segments of its 16 rows; segment lengths come from one byte per (tile, row).
+  the segments of its ``rpt`` rows; segment lengths come from 4 bits per (tile, row).
 
-Item = 4-byte value + 4-byte ``(slot << lw) | (col - panel*W)``.  Tiles are padded to multiples of 4 items
-(zero value, unused slot) so the kernel streams them with 16-byte loads.  Bytes per non-zero: 8 + RB*P/nnz_per_block
-(the count bytes): 8.8 for 100 non-zeros per row at 10M columns.
+Item = 4-byte value + 4-byte ``(slot << lw) | (col - panel*W)``.  Tiles are padded to multiples of 256 items
+(zero value, unused slot) and streamed with 16-byte loads.  Gather cost on gfx950 grows with the number of
+distinct 128-byte lines one wave instruction touches (about 3.4 clocks per line, measured), so inside every
+group of 256 column-sorted items the storage order is interleaved: position ``4*lane + j`` holds sorted item
+``64*j + lane``.  A lane's 16-byte load then yields items j = 0..3 of four different 64-item runs and gather
+instruction j covers 64 CONSECUTIVE sorted items (about 25 lines at 100 non-zeros per row) instead of 64 items
+spaced four apart (64 lines).  Bytes per non-zero: 8 + 20*512*P/nnz_per_block (the count nibbles): about 8.9 for 100 non-zeros per row at
+10M columns.
 
-A matrix is eligible when every tile holds at most ``cap`` items and no (tile, row) more than 255;
-otherwise ``build_tiles`` returns None and the CSR kernel is used.
+A matrix is eligible when it is float32, every tile holds at most ``cap`` items and no (tile, row) more than
+15; otherwise ``build_tiles`` returns None and the CSR kernel is used.
 """
 from __future__ import annotations
 
@@ -27,28 +32,36 @@ from typing import Optional
 
 import torch
 
-LW_DEFAULT = 17      # panel = 131072 columns
-LRB = 13             # 8192 rows per block = 512 threads x 16 rows (fixed by the kernel instantiation)
-CAP = 12288          # items per tile the kernel's LDS product buffer holds
+LW_DEFAULT = 16      # panel = 65536 columns (256 KB of f32: L2 resident on every XCD)
+NT = 512             # threads per workgroup (fixed by the kernel)
+RPT_MAX = 40         # most rows per thread
+CW = RPT_MAX // 8    # 32-bit words of 4-bit counts per (tile, thread)
+CAP = 16384          # items per tile each of the kernel's two LDS product buffers holds
+GROUP = 256          # tiles are padded to whole groups of 4 x 64 items (interleaved, see above)
+NCU = 512            # two workgroups per CU at a time: row blocks are sized to fill whole rounds
 
 
 @dataclass
 class Tiles:
     lw: int
-    lrb: int
+    rpt: int                 # rows per thread: a row block is 512*rpt rows
     cap: int
     nblk: int
     npanel: int
     nrows: int
     ncols: int
     idx: torch.Tensor        # int32 [items]  (slot << lw) | local column
-    val: torch.Tensor        # dtype [items]
-    tile_ptr: torch.Tensor   # int32 [nblk*npanel + 1], item offsets, multiples of 4
-    cnt: torch.Tensor        # uint8 [nblk*npanel*RB], non-zeros of each row of each tile
+    val: torch.Tensor        # float32 [items]
+    tile_ptr: torch.Tensor   # int32 [nblk*npanel + 1], item offsets, multiples of 256
+    cnt: torch.Tensor        # int32 [nblk*npanel*512*5]: 40 nibbles per (tile, thread)
 
     @property
     def items(self) -> int:
         return int(self.idx.numel())
+
+    @property
+    def rows_per_block(self) -> int:
+        return NT * self.rpt
 
     def bytes(self) -> int:
         return sum(int(t.numel()) * t.element_size() for t in (self.idx, self.val, self.tile_ptr, self.cnt))
@@ -59,25 +72,53 @@ def _wrap_i32(v: torch.Tensor) -> torch.Tensor:
     return torch.where(v >= 2 ** 31, v - 2 ** 32, v).to(torch.int32)
 
 
+def choose_rpt(nrows: int, nnz: int, ncols: int, lw: int, cap: int = CAP, ncu: int = NCU) -> int:
+    """Rows per thread: as many as the tile capacity allows (denser tiles = fewer cache lines per gather),
+    preferring a block count that fills whole rounds of one workgroup per CU."""
+    W = 1 << lw
+    per_row_panel = max(nnz / max(nrows, 1) * min(W, ncols) / max(ncols, 1), 1e-9)   # mean items of a row in a panel
+    best, best_score = 2, -1.0
+    for rpt in range(2, RPT_MAX + 1, 2):
+        rb = NT * rpt
+        mean_tile = rb * per_row_panel
+        if mean_tile + 6.0 * mean_tile ** 0.5 > cap and rpt > 2:      # keep 6 sigma below the LDS capacity
+            break
+        nblk = (nrows + rb - 1) // rb
+        rounds = (nblk + ncu - 1) // ncu
+        eff = nblk / (rounds * ncu)                                   # fill of the last round
+        score = eff * min(1.0, 0.35 + 0.65 * rpt / RPT_MAX)           # density matters, a ragged round matters more
+        if score > best_score:
+            best, best_score = rpt, score
+    return best
+
+
 def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, nrows: int, ncols: int,
-                lw: int = LW_DEFAULT, lrb: int = LRB, cap: int = CAP, max_chunk_nnz: int = 1 << 26) -> Optional[Tiles]:
+                lw: int = LW_DEFAULT, rpt: Optional[int] = None, cap: int = CAP, max_chunk_nnz: int = 1 << 26) -> Optional[Tiles]:
     """CSR (any row lengths, columns sorted or not) -> Tiles, or None when not eligible.  Runs on the
     tensors' device with torch sorts (setup cost, done once per matrix)."""
     dev = val.device
-    RB, W = 1 << lrb, 1 << lw
+    if val.dtype != torch.float32:
+        return None
+    nnz = int(colidx.numel())
+    W = 1 << lw
+    if rpt is None:
+        rpt = choose_rpt(nrows, nnz, ncols, lw, cap)
+    if rpt % 2 or not 2 <= rpt <= RPT_MAX:
+        raise ValueError("rpt must be even and <= 40")
+    RB = NT * rpt
     P = max(1, (ncols + W - 1) // W)
     NB = max(1, (nrows + RB - 1) // RB)
-    if cap + 4 > (1 << (32 - lw)):
-        raise ValueError("cap does not fit the slot field")
-    nnz = int(colidx.numel())
-    if nnz + 4 * NB * P >= 2 ** 31:
+    if cap + 4 > (1 << (32 - lw)) or cap > CAP:
+        raise ValueError("cap does not fit")
+    if nnz + GROUP * NB * P >= 2 ** 31:
         return None
     rp = rowptr.long()
     row_counts = rp[1:] - rp[:-1]
-    out_idx = torch.zeros(nnz + 4 * NB * P, dtype=torch.int32, device=dev)
-    out_val = torch.zeros(nnz + 4 * NB * P, dtype=val.dtype, device=dev)
+    out_idx = torch.zeros(nnz + GROUP * NB * P, dtype=torch.int32, device=dev)
+    out_val = torch.zeros(nnz + GROUP * NB * P, dtype=val.dtype, device=dev)
     tile_ptr = torch.zeros(NB * P + 1, dtype=torch.int64, device=dev)
-    cnt = torch.zeros(NB * P * RB, dtype=torch.uint8, device=dev)
+    cnt = torch.zeros(NB * P * NT * CW, dtype=torch.int32, device=dev)
+    shifts = (torch.arange(8, device=dev) * 4).view(1, 1, 1, 8)
     base = 0
     # chunks of whole row blocks with about max_chunk_nnz non-zeros
     blk_nnz = rp[torch.clamp(torch.arange(NB + 1, device=dev) * RB, max=nrows)].cpu().tolist()
@@ -95,15 +136,21 @@ def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, n
             cols = colidx[a:b].long()
             v = val[a:b]
             rloc = torch.repeat_interleave(torch.arange(r_hi - r_lo, device=dev), row_counts[r_lo:r_hi])
-            tile = (rloc >> lrb) * P + (cols >> lw)
+            rblk = rloc // RB
+            tile = rblk * P + (cols >> lw)
             tsz = torch.bincount(tile, minlength=ntl)
             if int(tsz.max()) > cap:
                 return None
-            c_tr = torch.bincount(tile * RB + (rloc & (RB - 1)), minlength=ntl * RB)
-            if int(c_tr.max()) > 255:
+            # items of every (tile, row): 4 bits each, 24 per thread (thread t owns rows t*rpt .. t*rpt+rpt-1)
+            c_tr = torch.bincount(tile * RB + (rloc - rblk * RB), minlength=ntl * RB)
+            if int(c_tr.max()) > 15:
                 return None
-            cnt[t0 * RB:(t0 + ntl) * RB] = c_tr.to(torch.uint8)
+            nib = torch.zeros(ntl, NT, RPT_MAX, dtype=torch.int64, device=dev)     # CW words = 40 nibbles per thread
+            nib[:, :, :rpt] = c_tr.view(ntl, NT, rpt)
             del c_tr
+            words = (nib.view(ntl, NT, CW, 8) << shifts).sum(-1)
+            cnt[t0 * NT * CW:(t0 + ntl) * NT * CW] = _wrap_i32(words.reshape(-1))
+            del nib, words
             tstart = torch.cumsum(tsz, 0) - tsz
             ar = torch.arange(n, device=dev)
             # slot = rank inside the tile in (row, column) order = CSR order restricted to the tile
@@ -116,7 +163,7 @@ def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, n
             order2 = torch.argsort(tile * W + lcol, stable=True)
             tile_s = tile[order2]
             packed = (slot[order2] << lw) | lcol[order2]
-            tsz_pad = (tsz + 3) // 4 * 4
+            tsz_pad = (tsz + GROUP - 1) // GROUP * GROUP
             pstart = torch.cumsum(tsz_pad, 0) - tsz_pad
             total = int(tsz_pad.sum())
             seg_i = out_idx[base:base + total]
@@ -126,20 +173,31 @@ def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, n
             dest = pstart[tile_s] + (ar - tstart[tile_s])
             seg_i[dest] = _wrap_i32(packed)
             seg_v[dest] = v[order2]
+            # interleave every 256-item group: physical 4*lane + j  <-  sorted 64*j + lane
+            seg_i.copy_(seg_i.view(-1, 4, 64).transpose(1, 2).reshape(-1))
+            seg_v.copy_(seg_v.view(-1, 4, 64).transpose(1, 2).reshape(-1))
             tile_ptr[t0:t0 + ntl] = base + pstart
             base += total
         else:
             tile_ptr[t0:t0 + ntl] = base
         b_lo = b_hi
     tile_ptr[NB * P] = base
-    return Tiles(lw, lrb, cap, NB, P, nrows, ncols, out_idx[:base].contiguous(), out_val[:base].contiguous(),
+    return Tiles(lw, rpt, cap, NB, P, nrows, ncols, out_idx[:base].contiguous(), out_val[:base].contiguous(),
                  tile_ptr.to(torch.int32), cnt)
+
+
+def tile_row_counts(t: Tiles, tile: int) -> torch.Tensor:
+    """items of each of the tile's 1024*rpt rows (unpacks the nibbles)"""
+    w = t.cnt[tile * NT * CW:(tile + 1) * NT * CW].long() & 0xFFFFFFFF
+    shifts = (torch.arange(8, device=w.device) * 4).view(1, 1, 8)
+    nib = (w.view(NT, CW, 1) >> shifts) & 15
+    return nib.reshape(NT, RPT_MAX)[:, :t.rpt].reshape(-1)
 
 
 def emulate_spmv(t: Tiles, x: torch.Tensor) -> torch.Tensor:
     """What the kernel computes, step by step, in torch on any device (tests only: pass 1 writes the
     products to their row-order slots, pass 2 sums each row's segment)."""
-    RB, W = 1 << t.lrb, 1 << t.lw
+    RB, W = t.rows_per_block, 1 << t.lw
     y = torch.zeros(t.nblk * RB, dtype=torch.float64, device=x.device)
     idx = t.idx.long() & 0xFFFFFFFF
     tp = t.tile_ptr.long().tolist()
@@ -154,7 +212,7 @@ def emulate_spmv(t: Tiles, x: torch.Tensor) -> torch.Tensor:
             xin = x[p * W:(p + 1) * W].double()
             lcol = pk & (W - 1)
             prod[pk >> t.lw] = t.val[i0:i1].double() * xin[lcol]
-            c = t.cnt[tile * RB:(tile + 1) * RB].long()
+            c = tile_row_counts(t, tile)
             ends = torch.cumsum(c, 0)
             csum = torch.cat([torch.zeros(1, dtype=torch.float64, device=x.device), torch.cumsum(prod[:int(ends[-1])], 0)])
             y[b * RB:(b + 1) * RB] += csum[ends] - csum[ends - c]
