@@ -1,0 +1,72 @@
+"""End-to-end on the GPU: MPS file -> solve_lp / CLI, against the reference's recorded afiro runs and HiGHS."""
+import csv
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import torchpdlp_amd as tp
+from tests.conftest import GOLDEN
+
+MPS_DIR = os.path.join(GOLDEN, "mps")
+AFIRO_OPT = -464.7531428571
+
+
+@pytest.mark.parametrize("mode", ["fixed_nopw_noruiz", "adaptive_pw_noruiz", "fixed_pw_ruiz", "adaptive_pw_ruiz"])
+def test_afiro_like_the_reference(golden, mode):
+    """BASELINE.json configs[0]: Netlib afiro through mps_to_standard_form + the solver, tol 1e-4."""
+    r = golden("afiro.npz").group(f"afiro/{mode}")
+    adaptive, pw, ruiz = mode.startswith("adaptive"), "_pw_" in mode, mode.endswith("_ruiz")
+    c, K, q, m_ineq, l, u = tp.mps_to_standard_form(os.path.join(MPS_DIR, "afiro.mps"), device="cuda:0")
+    dp = None
+    Ks, cs, qs, ls, us = K, c, q, l, u
+    if ruiz:
+        Ks, cs, qs, ls, us, dp, _ = tp.ruiz_precondition(c, K, q, l, u, device="cuda:0")
+    b0 = torch.tensor(r["b0"], device="cuda:0")
+    x, obj, k, n, j, status, _ = tp.pdlp_algorithm(Ks, m_ineq, cs, qs, ls, us, "cuda:0", max_kkt=400_000, tol=1e-4, verbose=False,
+                                                   precondition=ruiz, primal_update=pw, adaptive=adaptive, data_precond=dp, b0=b0)
+    assert status == "Solved" == str(r["status"])
+    assert abs(obj - AFIRO_OPT) <= 1e-3 * (1 + abs(AFIRO_OPT))                  # SURVEY 8d cfg 1
+    assert abs(obj - float(r["obj"])) <= 2e-3 * (1 + abs(AFIRO_OPT))
+    assert abs(k - int(r["k"])) <= 0.6 * int(r["k"]) + 80
+    if mode == "fixed_nopw_noruiz":
+        assert (k, n, j) == (int(r["k"]), int(r["n"]), int(r["j"]))             # same restart trace as the reference
+        np.testing.assert_allclose(x.cpu().numpy().ravel(), r["x"], rtol=2e-3, atol=2e-3)
+
+
+def test_solve_lp_unscales_and_is_feasible():
+    res = tp.solve_lp(os.path.join(MPS_DIR, "afiro.mps"), precondition=True, primal_weight_update=True, adaptive_stepsize=True, seed=3)
+    assert res.status == "Solved" and abs(res.objective - AFIRO_OPT) <= 1e-3 * (1 + abs(AFIRO_OPT))
+    c, K, q, m_ineq, l, u = tp.mps_to_standard_form(os.path.join(MPS_DIR, "afiro.mps"), device="cuda:0")
+    x = res.x.double()
+    assert abs(float((c.double() * x).sum()) - res.objective) <= 1e-2           # x is the ORIGINAL problem's point
+    r = K.to_dense().double() @ x - q.double()
+    viol = torch.cat([r[:m_ineq].clamp(max=0), r[m_ineq:]])
+    assert float(viol.norm()) <= 2e-4 * (1 + float(q.norm()))
+    assert res.as_tuple()[2:6] == (res.iterations, res.restarts, res.kkt_passes, res.status)
+    # arrays instead of a path, dense K as the reference passes it
+    res2 = tp.solve_lp((c, K.to_dense(), q, m_ineq, l, u), adaptive_stepsize=True, seed=3)
+    assert res2.status == "Solved" and abs(res2.objective - AFIRO_OPT) <= 1e-3 * (1 + abs(AFIRO_OPT))
+
+
+def test_float64_reaches_a_tolerance_below_float32_resolution():
+    res = tp.solve_lp(os.path.join(MPS_DIR, "afiro.mps"), tol=1e-8, precondition=True, primal_weight_update=True,
+                      adaptive_stepsize=True, dtype=torch.float64, seed=3, max_kkt=2_000_000)
+    assert res.status == "Solved" and abs(res.objective - AFIRO_OPT) <= 1e-6
+
+
+def test_cli_writes_the_reference_csv_schema(tmp_path):
+    from torchpdlp_amd.__main__ import COLUMNS, main
+    rc = main(["--instance_path", MPS_DIR, "--output_path", str(tmp_path), "--adaptive_stepsize", "--primal_weight_update",
+               "--seed", "1", "--max_kkt", "200000"])
+    assert rc == 0
+    rows = list(csv.DictReader(open(tmp_path / "solver_results.csv")))
+    assert list(rows[0].keys()) == COLUMNS
+    by = {r["File"]: r for r in rows}
+    assert sorted(by) == ["afiro.mps", "all_eq.mps", "all_ineq.mps", "features.mps", "marker.mps"]
+    assert by["afiro.mps"]["Status"] == "Solved" and abs(float(by["afiro.mps"]["Objective"]) - AFIRO_OPT) < 0.5
+    assert by["marker.mps"]["Status"].startswith("Solver failed: could not convert string to float")   # and the run went on
+    assert by["all_eq.mps"]["Status"] == "Solved" and by["all_ineq.mps"]["Status"] == "Solved"

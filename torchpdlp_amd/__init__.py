@@ -14,5 +14,7 @@ from .ops import (KKT_error, adaptive_one_step_pdhg, compute_residuals_and_duali
                   fixed_one_step_pdhg, primal_weight_update, spectral_norm_estimate_torch)
 from .precondition import ruiz_precondition                              # noqa: F401
 from .synthetic import SyntheticLP, gen_lp                               # noqa: F401
+from .mps import mps_to_standard_form, parse_mps                         # noqa: F401
+from .api import LPResult, solve_lp                                      # noqa: F401
 
 __version__ = "0.1.0"

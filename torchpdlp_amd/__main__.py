@@ -1,0 +1,88 @@
+"""Batch driver with the reference's command line and CSV schema (``/root/reference/PDLP/main.py:11-174``):
+
+    python -m torchpdlp_amd --instance_path DIR [--tolerance 1e-4] [--output_path output] [--precondition]
+        [--primal_weight_update] [--adaptive_stepsize] [--verbose] [--max_kkt N] [--time_limit S]
+
+Solves every ``*.mps`` in the folder (sorted), continues past failures and writes ``solver_results.csv`` with the
+columns ``File, Objective, Iterations (k), Restarts (n), KKT Passes (j), Time (s), Status``.
+"""
+import argparse
+import csv
+import os
+import sys
+
+import torch
+
+from .api import solve_lp
+
+COLUMNS = ["File", "Objective", "Iterations (k)", "Restarts (n)", "KKT Passes (j)", "Time (s)", "Status"]
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="Run the MI355X PDLP solver over a folder of MPS instances.")
+    p.add_argument("--device", type=str, choices=["cpu", "gpu", "auto"], default="auto",
+                   help="kept for compatibility; the solver runs on the HIP device (there is no CPU path)")
+    p.add_argument("--instance_path", type=str, default="feasible")
+    p.add_argument("--tolerance", type=float, default=1e-4)
+    p.add_argument("--output_path", type=str, default="output")
+    p.add_argument("--precondition", action="store_true")
+    p.add_argument("--primal_weight_update", action="store_true")
+    p.add_argument("--adaptive_stepsize", action="store_true")
+    p.add_argument("--infeasibility_detect", action="store_true")
+    p.add_argument("--verbose", action="store_true")
+    p.add_argument("--support_sparse", action="store_true", help="accepted; matrices are always sparse here")
+    p.add_argument("--max_kkt", type=int, default=100_000)
+    p.add_argument("--time_limit", type=int, default=3600)
+    p.add_argument("--fishnet", action="store_true")
+    p.add_argument("--dtype", choices=["fp32", "fp64"], default="fp32", help="fp64 for tolerances below float32 resolution")
+    p.add_argument("--seed", type=int, default=None, help="pins the power-iteration start vector (unseeded in the reference)")
+    p.add_argument("--standard_mps", action="store_true", help="standard meaning of FR/MI/PL/BV bounds instead of the reference's")
+    return p.parse_args(argv)
+
+
+def _fail_row(name, what, e):
+    msg = str(e)
+    status = f"{what}: {msg[:50]}..." if len(msg) > 50 else f"{what}: {msg}"     # main.py:101,161
+    return {"File": name, "Objective": "N/A", "Iterations (k)": "N/A", "Restarts (n)": "N/A", "KKT Passes (j)": "N/A",
+            "Time (s)": "N/A", "Status": status}
+
+
+def main(argv=None) -> int:
+    args = parse_args(argv)
+    if args.device == "cpu" or not torch.cuda.is_available():
+        print("torchpdlp_amd needs a HIP device: there is no CPU solver path in this package.", file=sys.stderr)
+        return 2
+    print(f"PyTorch is using ROCm/CUDA device: {torch.cuda.get_device_name(0)}")
+    files = sorted(f for f in os.listdir(args.instance_path) if f.endswith(".mps"))       # main.py:83
+    results = []
+    for name in files:
+        path = os.path.join(args.instance_path, name)
+        print(f"\nProcessing {path}...")
+        try:
+            if args.fishnet or args.infeasibility_detect:
+                raise NotImplementedError("fishnet / infeasibility detection are outside the accelerated hot path")
+            r = solve_lp(path, tol=args.tolerance, precondition=args.precondition, primal_weight_update=args.primal_weight_update,
+                         adaptive_stepsize=args.adaptive_stepsize, max_kkt=args.max_kkt, time_limit=args.time_limit,
+                         verbose=args.verbose, dtype=torch.float32 if args.dtype == "fp32" else torch.float64, seed=args.seed,
+                         compat=not args.standard_mps)
+            print(f"Solver uses {r.time:.4f} seconds.\nStatus: {r.status}")
+            results.append({"File": name, "Objective": f"{r.objective:.6f}", "Iterations (k)": r.iterations, "Restarts (n)": r.restarts,
+                            "KKT Passes (j)": r.kkt_passes, "Time (s)": f"{r.time:.4f}", "Status": r.status})      # main.py:142-150
+        except Exception as e:          # the reference records the failure and goes on (main.py:152-162)
+            print(f"Solver failed for {name}. Error: {e}")
+            results.append(_fail_row(name, "Solver failed", e))
+    os.makedirs(args.output_path, exist_ok=True)
+    if results:
+        out = os.path.join(args.output_path, "solver_results.csv")
+        with open(out, "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=COLUMNS)
+            w.writeheader()
+            w.writerows(results)
+        print(f"Results saved to CSV instead: {out}")
+    else:
+        print("No results to save.")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

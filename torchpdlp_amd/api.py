@@ -1,0 +1,60 @@
+"""``solve_lp``: one call from an MPS file (or arrays) to a solution, the flow of the reference's driver
+(``/root/reference/PDLP/main.py:85-137``) and of its older ``pdlp_solver`` wrapper
+(``/root/reference/Packages/PDLP_without_presolve_infeasibility.py:748-789``) on the MI355X path."""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import Optional, Union
+
+import torch
+
+from .mps import mps_to_standard_form
+from .precondition import ruiz_precondition
+from .solver import pdlp_algorithm
+from .sparse import CsrPair
+
+
+@dataclass
+class LPResult:
+    x: torch.Tensor            # (n, 1) primal solution of the ORIGINAL problem (un-scaled when preconditioned)
+    objective: float           # c'x of the original problem
+    iterations: int            # k
+    restarts: int              # n
+    kkt_passes: int            # j
+    status: str                # "Solved" | "Unsolved (KKT passes limit exceeded)" | "Unsolved (Time limit exceeded)"
+    time: float                # seconds, preconditioning included (main.py:107,136)
+
+    def as_tuple(self):
+        """the reference's result tuple (pdhg.py:181)"""
+        return self.x, self.objective, self.iterations, self.restarts, self.kkt_passes, self.status, self.time
+
+
+def solve_lp(problem: Union[str, os.PathLike, tuple], device=None, tol: float = 1e-4, precondition: bool = False,
+             primal_weight_update: bool = False, adaptive_stepsize: bool = False, max_kkt: int = 100_000,
+             time_limit: float = 3600, verbose: bool = False, restart_period: int = 40, dtype=torch.float32,
+             seed: Optional[int] = None, compat: bool = True, x_init=None, y_init=None, trace=None) -> LPResult:
+    """Solve ``min c'x, K[:m_ineq]x >= q[:m_ineq], K[m_ineq:]x = q[m_ineq:], l <= x <= u`` on the current HIP device.
+
+    ``problem`` is an MPS path or ``(c, K, q, m_ineq, l, u)`` with ``K`` dense / COO / scipy-sparse / ``CsrPair``.
+    Flags carry the reference CLI's names (main.py:11-39).  ``dtype=torch.float64`` is the mode for tolerances
+    below float32 resolution (the reference is float32 only).
+    """
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if isinstance(problem, (str, os.PathLike)):
+        c, K, q, m_ineq, l, u = mps_to_standard_form(os.fspath(problem), device=device, verbose=verbose, compat=compat, dtype=dtype)
+    else:
+        c, K, q, m_ineq, l, u = problem
+        K = CsrPair.from_any(K, device=device, dtype=dtype)
+    time_used, data_precond = 0.0, None
+    Ks, cs, qs, ls, us = K, c, q, l, u
+    if precondition:                                                    # main.py:106-110
+        Ks, cs, qs, ls, us, data_precond, time_used = ruiz_precondition(c, K, q, l, u, device=device)
+    x, obj, k, n, j, status, total = pdlp_algorithm(
+        Ks, m_ineq, cs, qs, ls, us, device, max_kkt=max_kkt, tol=tol, verbose=verbose, restart_period=restart_period,
+        precondition=precondition, primal_update=primal_weight_update, adaptive=adaptive_stepsize,
+        data_precond=data_precond, time_limit=time_limit, time_used=time_used, x_init=x_init, y_init=y_init, seed=seed,
+        trace=trace)
+    if precondition:        # the reference returns the scaled iterate (quirk Q4); solve_lp un-scales: x = D_col x_s (pdhg.py:161)
+        x = data_precond[0].view(-1, 1).to(x.dtype) * x
+    return LPResult(x, obj, k, n, j, status, total)
