@@ -55,7 +55,7 @@ def test_solve_lp_unscales_and_is_feasible():
 def test_float64_reaches_a_tolerance_below_float32_resolution():
     res = tp.solve_lp(os.path.join(MPS_DIR, "afiro.mps"), tol=1e-8, precondition=True, primal_weight_update=True,
                       adaptive_stepsize=True, dtype=torch.float64, seed=3, max_kkt=2_000_000)
-    assert res.status == "Solved" and abs(res.objective - AFIRO_OPT) <= 1e-6
+    assert res.status == "Solved" and abs(res.objective - AFIRO_OPT) <= 2e-8 * (1 + 2 * abs(AFIRO_OPT))   # gap test: 1e-8 (1+|p|+|d|)
 
 
 def test_cli_writes_the_reference_csv_schema(tmp_path):
