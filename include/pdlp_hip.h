@@ -84,6 +84,8 @@ typedef struct pdlp_problem {
 typedef struct pdlp_tiles {
     int32_t lw, rpt, cap;       /* panel = 2^lw columns; rows per thread (even, <= 40); most items per tile  */
     int32_t nblk, npanel;       /* row blocks, column panels                                               */
+    int32_t groups;             /* workgroups sharing a row block, each walking ceil(npanel/groups) panels; 1 = the
+                                   epilogue is fused, > 1 (<= 8, <= npanel) = partial row sums + k_rowsum_epilogue */
     const uint32_t* idx;        /* [items]                                                                 */
     const void* val;            /* [items] float32                                                         */
     const int32_t* tile_ptr;    /* [nblk*npanel + 1] item offsets, multiples of 256                        */

@@ -466,6 +466,13 @@ def test_tiled_spmv_matches_oracle(shape):
     close(eng.spmv(dev(y), True), o.spmv(y, True), 2e-5)
     eng.attach_tiles(0, None)                   # detaching returns to the CSR kernel
     close(eng.spmv(dev(x), False), o.spmv(x, False), 2e-5)
+    # the same row blocks shared by several workgroups (panels split into groups) + the separate epilogue kernel
+    if shape in ("multi_panel_multi_block", "wide100", "ragged_ok"):
+        for groups in (2, 3, 8):
+            t = build_tiles(eng.K[0], eng.K[1], eng.K[2], m, n, groups=groups)
+            assert t.groups == min(groups, t.npanel, 8)
+            eng.attach_tiles(0, t)
+            close(eng.spmv(dev(x), False), o.spmv(x, False), 2e-5)
 
 
 def test_tiled_engine_steps_and_kkt_match_csr_engine(monkeypatch):
@@ -477,6 +484,7 @@ def test_tiled_engine_steps_and_kkt_match_csr_engine(monkeypatch):
     monkeypatch.setenv("PDLP_TILED", "1")
     e1 = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
     assert e0.tiles == [None, None] and all(t is not None for t in e1.tiles)
+    assert e1.tiles[0].groups > 1           # 250k rows: the panels of a row block are split over several workgroups
     g = torch.Generator(device=DEV).manual_seed(1)
     x0 = torch.minimum(torch.maximum(torch.randn(lp.n, device=DEV, generator=g), lp.l), lp.u)
     y0 = torch.randn(lp.m, device=DEV, generator=g)

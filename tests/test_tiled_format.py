@@ -5,7 +5,7 @@ import pytest
 import scipy.sparse as sp
 import torch
 
-from torchpdlp_amd.tiled import NT, build_tiles, choose_rpt, emulate_spmv, tile_row_counts
+from torchpdlp_amd.tiled import NT, build_tiles, choose_rpt, choose_shape, emulate_spmv, tile_row_counts
 
 
 def _csr(m, n, lens, seed):
@@ -75,3 +75,8 @@ def test_choose_rpt_fills_whole_rounds():
     assert rpt % 2 == 0 and 512 * rpt * 0.6554 * 1.06 < 16384
     assert nblk / (512 * -(-nblk // 512)) > 0.9
     assert choose_rpt(1000, 3000, 1000, 16) >= 2
+    assert choose_shape(10_000_000, 1_000_000_000, 10_000_000, 16) == (rpt, 1)
+    # one rank's shard of the same problem on 8 GPUs: big row blocks, panels split over 8 workgroups
+    rpt8, g8 = choose_shape(1_250_000, 125_000_000, 10_000_000, 16)
+    assert rpt8 >= 32 and g8 == 8 and 0.9 < -(-1_250_000 // (512 * rpt8)) * g8 / 512 <= 1.0
+    assert choose_shape(100, 300, 50, 16) == (choose_rpt(100, 300, 50, 16), 1)          # a single panel cannot be split

@@ -34,7 +34,7 @@ class PdlpProblem(C.Structure):
 class PdlpTiles(C.Structure):
     """mirror of ``struct pdlp_tiles``"""
     _fields_ = [("lw", C.c_int32), ("rpt", C.c_int32), ("cap", C.c_int32), ("nblk", C.c_int32), ("npanel", C.c_int32),
-                ("idx", C.c_void_p), ("val", C.c_void_p), ("tile_ptr", C.c_void_p), ("cnt", C.c_void_p)]
+                ("groups", C.c_int32), ("idx", C.c_void_p), ("val", C.c_void_p), ("tile_ptr", C.c_void_p), ("cnt", C.c_void_p)]
 
 
 # every symbol include/pdlp_hip.h declares: name -> (restype, argtypes)

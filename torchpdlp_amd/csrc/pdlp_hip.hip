@@ -253,57 +253,71 @@ constexpr int TCAP = 16384;              // most items per tile
 constexpr int TU = 4;                    // 16-byte chunks per thread and register group
 constexpr int TGRP = TNT * 4 * TU;       // items per register group
 
-struct F4 { float x, y, z, w; };
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <class Epi>
+// FUSED: the workgroup walks ALL panels of its row block and runs the epilogue itself.  Otherwise the panels of
+// a row block are split over `groups` workgroups (blockIdx = group * nblk + row block; needed when there are too
+// few rows for one workgroup per row block to fill the chip, e.g. one rank's shard of a sharded problem): each
+// writes its partial row sums to rowsum[group] and k_rowsum_epilogue adds them in fixed order.
+template <class Epi, bool FUSED>
 __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restrict__ tidx, const float* __restrict__ tval,
                                                         const int32_t* __restrict__ tile_ptr, const uint32_t* __restrict__ tcnt,
-                                                        int npanel, int lw, int rpt, int nrows, const float* __restrict__ vin,
-                                                        float* __restrict__ rowsum, Epi epi, double* __restrict__ partials)
+                                                        int npanel, int lw, int rpt, int nrows, int nblk, int ppg,
+                                                        const float* __restrict__ vin, float* __restrict__ rowsum,
+                                                        int64_t rs_stride, Epi epi, double* __restrict__ partials)
 {
     __shared__ __attribute__((aligned(16))) float prod[TCAP + 8];
     __shared__ int wsum[TNT / 64];
     __shared__ double dred8[TNT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int b = blockIdx.x;
+    const int b = FUSED ? blockIdx.x : blockIdx.x % nblk;
+    const int grp = FUSED ? 0 : blockIdx.x / nblk;
+    const int p_lo = grp * ppg, p_hi = (p_lo + ppg < npanel) ? p_lo + ppg : npanel;
     const uint32_t mask = (1u << lw) - 1u;
-    epi.load();
+    if (FUSED) epi.load();
     float acc[TRPT_MAX];
 #pragma unroll
     for (int r = 0; r < TRPT_MAX; ++r) acc[r] = 0.0f;
 
-    uint4 pk[TU];
-    F4 vv[TU];
+    u32x4 pk[TU];
+    f32x4 vv[TU];
     const uint32_t trash = (uint32_t)TCAP << lw;       // slot TCAP (past every real slot), column 0
+    // the item stream is read once: non-temporal loads keep it from evicting the gathered panel out of the L2
     auto load_group = [&](int g0, int i1) {
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
             const int i = g0 + (u * TNT + tid) * 4;
             if (i < i1) {
-                pk[u] = *reinterpret_cast<const uint4*>(tidx + i);
-                vv[u] = *reinterpret_cast<const F4*>(tval + i);
+#ifdef PDLP_TEMPORAL_STREAM
+                pk[u] = *reinterpret_cast<const u32x4*>(tidx + i);
+                vv[u] = *reinterpret_cast<const f32x4*>(tval + i);
+#else
+                pk[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(tidx + i));
+                vv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(tval + i));
+#endif
             } else {
-                pk[u] = make_uint4(trash, trash, trash, trash);
-                vv[u] = F4{0.0f, 0.0f, 0.0f, 0.0f};
+                pk[u] = u32x4{trash, trash, trash, trash};
+                vv[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             }
         }
     };
     const size_t tile0 = (size_t)b * npanel;
-    int i0 = tile_ptr[tile0];
-    int i1 = tile_ptr[tile0 + 1];
+    int i0 = tile_ptr[tile0 + p_lo];
+    int i1 = tile_ptr[tile0 + p_lo + 1];
     load_group(i0, i1);
 
-    for (int p = 0; p < npanel; ++p) {
+    for (int p = p_lo; p < p_hi; ++p) {
         const size_t tile = tile0 + p;
         const float* __restrict__ xin = vin + ((size_t)p << lw);
-        const int i0n = i1, i1n = p + 1 < npanel ? tile_ptr[tile + 2] : i1;     // the next tile (empty after the last)
+        const int i0n = i1, i1n = p + 1 < p_hi ? tile_ptr[tile + 2] : i1;       // the next tile (empty after the last)
         // segment lengths of this thread's rows (4 bits each) and their offset inside the wave
         uint32_t cw[TCW];
         const uint32_t* cp = tcnt + (tile * TNT + tid) * TCW;
         int total = 0;
 #pragma unroll
         for (int q = 0; q < TCW; ++q) {
-            cw[q] = cp[q];
+            cw[q] = __builtin_nontemporal_load(cp + q);
             const uint32_t n2 = (cw[q] & 0x0f0f0f0fu) + ((cw[q] >> 4) & 0x0f0f0f0fu);
             total += (int)((n2 * 0x01010101u) >> 24);
         }
@@ -369,10 +383,11 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
     // per row, L2 resident) so that the epilogue runs with consecutive lanes on consecutive rows and all of
     // its vector traffic is coalesced.  (The 512*40 sums do not fit the 64 KB product buffer.)
     const int rb = TNT * rpt;
-    float* __restrict__ rs = rowsum + (size_t)b * rb;
+    float* __restrict__ rs = rowsum + (size_t)grp * rs_stride + (size_t)b * rb;
 #pragma unroll
     for (int r = 0; r < TRPT_MAX; ++r)
         if (r < rpt) rs[tid * rpt + r] = acc[r];
+    if (!FUSED) return;
     __threadfence_block();
     __syncthreads();
     double accd[NACC] = {0.0, 0.0, 0.0, 0.0};
@@ -395,6 +410,28 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
                 for (int w = 0; w < TNT / 64; ++w) t += dred8[w];
                 partials[(size_t)b * NACC + r] = t;
             }
+        }
+    }
+}
+
+// epilogue of the split tiled kernel: row sum = sum over panel groups (fixed order), then the fused vector update
+template <class Epi>
+__global__ __launch_bounds__(BLOCK) void k_rowsum_epilogue(const float* __restrict__ rowsum, int groups, int64_t rs_stride,
+                                                           int nrows, Epi epi, double* __restrict__ partials)
+{
+    __shared__ double dred[4];
+    epi.load();
+    double acc[NACC] = {0.0, 0.0, 0.0, 0.0};
+    for (int row = blockIdx.x * BLOCK + threadIdx.x; row < nrows; row += gridDim.x * BLOCK) {
+        float s = __builtin_nontemporal_load(rowsum + row);
+        for (int g = 1; g < groups; ++g) s += __builtin_nontemporal_load(rowsum + (size_t)g * rs_stride + row);
+        epi(row, s, acc);
+    }
+    if (Epi::NA > 0) {
+#pragma unroll
+        for (int r = 0; r < Epi::NA; ++r) {
+            const double v = block_sum(acc[r], dred);
+            if (threadIdx.x == 0) partials[(size_t)blockIdx.x * NACC + r] = v;
         }
     }
 }
@@ -684,7 +721,9 @@ struct pdlp_solver {
     char* kxb[3];                 // K x caches: [0] running, [1] from KKT(cur), [2] from KKT(avg)
     bool kx_valid, cand_valid[2];
     double *partA, *partB, *red, *sc;
-    float* rowsum;                // row sums of the tiled kernel on their way to the epilogue (rows + one row block)
+    float* rowsum;                // row sums of the tiled kernel on their way to the epilogue: [groups][rs_stride]
+    int64_t rs_stride;            // rows + one row block
+    int rs_groups;                // panel groups the scratch has room for
     int last_gridA, last_gridB;   // grids of the last primal / dual launch (adaptive reduce)
 };
 
@@ -696,9 +735,19 @@ int launch_csr(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* 
     const Schedule& s = transpose ? h->sKT : h->sK;
     if (s.nblk == 0) return PDLP_OK;
     if constexpr (sizeof(T) == 4) if (s.tiled) {
-        hipLaunchKernelGGL((k_tiled_fused<Epi>), dim3(s.t.nblk), dim3(TNT), 0, h->stream, s.t.idx, (const float*)s.t.val,
-                           s.t.tile_ptr, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, (int)(transpose ? h->nl : h->ml),
-                           (const float*)vin, h->rowsum, epi, partials);
+        const int rows = (int)(transpose ? h->nl : h->ml);
+        const int ppg = (s.t.npanel + s.t.groups - 1) / s.t.groups;
+        if (s.t.groups == 1) {
+            hipLaunchKernelGGL((k_tiled_fused<Epi, true>), dim3(s.t.nblk), dim3(TNT), 0, h->stream, s.t.idx, (const float*)s.t.val,
+                               s.t.tile_ptr, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, ppg, (const float*)vin,
+                               h->rowsum, h->rs_stride, epi, partials);
+        } else {
+            hipLaunchKernelGGL((k_tiled_fused<Epi, false>), dim3(s.t.nblk * s.t.groups), dim3(TNT), 0, h->stream, s.t.idx,
+                               (const float*)s.t.val, s.t.tile_ptr, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, ppg,
+                               (const float*)vin, h->rowsum, h->rs_stride, epi, partials);
+            hipLaunchKernelGGL((k_rowsum_epilogue<Epi>), dim3(grid_for(rows)), dim3(BLOCK), 0, h->stream, h->rowsum, s.t.groups,
+                               h->rs_stride, rows, epi, partials);
+        }
         HIP_TRY(hipGetLastError());
         return PDLP_OK;
     }
@@ -711,7 +760,12 @@ int launch_csr(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* 
     return PDLP_OK;
 }
 
-inline int grid_of(const Schedule& s) { return s.nblk == 0 ? 0 : (s.tiled ? s.t.nblk : s.grid); }
+inline int grid_of(const Schedule& s, int64_t rows)
+{
+    if (s.nblk == 0) return 0;
+    if (!s.tiled) return s.grid;
+    return s.t.groups == 1 ? s.t.nblk : grid_for(rows);      // split tiles: the partial sums come from k_rowsum_epilogue
+}
 
 template <typename T> T* xloc(pdlp_handle h, int ix) { return (T*)h->xb[ix] + h->p.col0; }
 template <typename T> T* yloc(pdlp_handle h, int ix) { return (T*)h->yb[ix] + h->p.row0; }
@@ -722,7 +776,7 @@ template <typename T> int primal_half_t(pdlp_handle h, int adaptive)
     if (adaptive) {
         PrimalEpi<T, true> e{xloc<T>(h, h->ix_cur), xloc<T>(h, h->ix_prev), (T*)h->xbar + h->p.col0, (const T*)h->p.c,
                              (const T*)h->p.l, (const T*)h->p.u, (T*)h->x_sum, sc};
-        h->last_gridA = grid_of(h->sKT);
+        h->last_gridA = grid_of(h->sKT, h->nl);
         return launch_csr<T>(h, true, h->yb[h->ix_cur], e, h->partA);
     }
     PrimalEpi<T, false> e{xloc<T>(h, h->ix_cur), xloc<T>(h, h->ix_prev), (T*)h->xbar + h->p.col0, (const T*)h->p.c,
@@ -745,7 +799,7 @@ template <typename T> int dual_half_t(pdlp_handle h, int adaptive)
         if (!h->kx_valid && (rc = refresh_kx_t<T>(h)) != PDLP_OK) return rc;
         DualEpi<T, true> e{yloc<T>(h, h->ix_cur), yloc<T>(h, h->ix_prev), (const T*)h->p.q, (T*)h->y_sum, (T*)h->kxb[0],
                            h->sc, h->ineq_end};
-        h->last_gridB = grid_of(h->sK);
+        h->last_gridB = grid_of(h->sK, h->ml);
         rc = launch_csr<T>(h, false, h->xbar, e, h->partB);
     } else {
         DualEpi<T, false> e{yloc<T>(h, h->ix_cur), yloc<T>(h, h->ix_prev), (const T*)h->p.q, (T*)h->y_sum, (T*)h->kxb[0],
@@ -777,8 +831,8 @@ template <typename T> int kkt_local_t(pdlp_handle h, int which, int unscaled)
         KktPrimalEpi<T, false> ep{yloc<T>(h, ix), (const T*)h->p.q, nullptr, kx_out, h->ineq_end};
         if ((rc = launch_csr<T>(h, false, h->xb[ix], ep, h->partB)) != PDLP_OK) return rc;
     }
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partA, grid_of(h->sKT), 4, h->red, 0);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partB, grid_of(h->sK), 2, h->red, 4);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partA, grid_of(h->sKT, h->nl), 4, h->red, 0);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partB, grid_of(h->sK, h->ml), 2, h->red, 4);
     HIP_TRY(hipGetLastError());
     if (which != PDLP_PREV) h->cand_valid[which == PDLP_CUR ? 0 : 1] = true;
     return PDLP_OK;
@@ -875,6 +929,10 @@ int check_problem(const pdlp_problem* p)
     return PDLP_OK;
 }
 
+// panel groups the row-sum scratch is sized for: splitting only pays when one workgroup per (largest) row block
+// cannot fill 2 x 256 CUs, i.e. below about 10.5M rows
+inline int64_t rowsum_groups(int64_t rows) { return rows <= (int64_t)TNT * TRPT_MAX * 512 ? 8 : 1; }
+
 struct Carve {
     int64_t off = 0;
     int64_t take(int64_t bytes) { const int64_t o = off; off = align_up(off + bytes, 256); return o; }
@@ -902,7 +960,7 @@ int64_t layout(const pdlp_problem* p, int64_t nnzK, int64_t nnzKT, int64_t* offs
     offs[k++] = c.take(PDLP_NSCAL * 8);                           // 17    sc
     offs[k++] = c.take((max_blocks(ml, nnzK) + 1) * 4);           // 18    schedule K
     offs[k++] = c.take((max_blocks(nl, nnzKT) + 1) * 4);          // 19    schedule K'
-    offs[k++] = c.take(((nl > ml ? nl : ml) + (int64_t)TNT * TRPT_MAX) * 4);   // 20  rowsum scratch (tiled kernel)
+    offs[k++] = c.take(rowsum_groups(nl > ml ? nl : ml) * ((nl > ml ? nl : ml) + (int64_t)TNT * TRPT_MAX) * 4);   // 20  rowsum scratch
     return c.off;
 }
 
@@ -982,6 +1040,8 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     h->red = (double*)(w + offs[16]); h->sc = (double*)(w + offs[17]);
     h->sK.blk = (int32_t*)(w + offs[18]); h->sKT.blk = (int32_t*)(w + offs[19]);
     h->rowsum = (float*)(w + offs[20]);
+    h->rs_stride = (nl > ml ? nl : ml) + (int64_t)TNT * TRPT_MAX;
+    h->rs_groups = (int)rowsum_groups(nl > ml ? nl : ml);
     h->kx_valid = false; h->cand_valid[0] = h->cand_valid[1] = false;
     h->last_gridA = h->last_gridB = 0;
 
@@ -1041,6 +1101,7 @@ int pdlp_attach_tiles(pdlp_handle h, int transpose, const pdlp_tiles* t)
     if (t->rpt < 2 || t->rpt > TRPT_MAX || (t->rpt & 1) || t->cap > TCAP || t->lw < 4 || t->lw > 16) return PDLP_ERR_INVALID;
     const int64_t rb = (int64_t)TNT * t->rpt;
     if (t->nblk != (int)((rows + rb - 1) / rb) || t->npanel < 1) return PDLP_ERR_INVALID;
+    if (t->groups < 1 || t->groups > h->rs_groups || t->groups > t->npanel) return PDLP_ERR_INVALID;
     if (!t->idx || !t->val || !t->tile_ptr || !t->cnt) return PDLP_ERR_INVALID;
     if (((uintptr_t)t->idx & 15u) || ((uintptr_t)t->val & 15u) || ((uintptr_t)t->cnt & 3u)) return PDLP_ERR_INVALID;
     s.t = *t;

@@ -141,7 +141,7 @@ class PdlpEngine:
             N.check(self.lib.pdlp_attach_tiles(self.h, int(transpose), None), "pdlp_attach_tiles")
             self.tiles[int(transpose)] = None
             return
-        desc = N.PdlpTiles(t.lw, t.rpt, t.cap, t.nblk, t.npanel, t.idx.data_ptr(), t.val.data_ptr(), t.tile_ptr.data_ptr(),
+        desc = N.PdlpTiles(t.lw, t.rpt, t.cap, t.nblk, t.npanel, t.groups, t.idx.data_ptr(), t.val.data_ptr(), t.tile_ptr.data_ptr(),
                            t.cnt.data_ptr())
         N.check(self.lib.pdlp_attach_tiles(self.h, int(transpose), C.byref(desc)), "pdlp_attach_tiles")
         self.tiles[int(transpose)] = t       # keep the arrays alive

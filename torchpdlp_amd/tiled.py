@@ -54,6 +54,7 @@ class Tiles:
     val: torch.Tensor        # float32 [items]
     tile_ptr: torch.Tensor   # int32 [nblk*npanel + 1], item offsets, multiples of 256
     cnt: torch.Tensor        # int32 [nblk*npanel*512*5]: 40 nibbles per (tile, thread)
+    groups: int = 1          # workgroups sharing a row block (each walks ceil(npanel/groups) panels)
 
     @property
     def items(self) -> int:
@@ -72,28 +73,38 @@ def _wrap_i32(v: torch.Tensor) -> torch.Tensor:
     return torch.where(v >= 2 ** 31, v - 2 ** 32, v).to(torch.int32)
 
 
-def choose_rpt(nrows: int, nnz: int, ncols: int, lw: int, cap: int = CAP, ncu: int = NCU) -> int:
-    """Rows per thread: as many as the tile capacity allows (denser tiles = fewer cache lines per gather),
-    preferring a block count that fills whole rounds of one workgroup per CU."""
+def choose_shape(nrows: int, nnz: int, ncols: int, lw: int, cap: int = CAP, slots: int = NCU, max_groups: int = 8):
+    """(rows per thread, panel groups).  Denser tiles mean fewer cache lines per gather, so take as many rows per
+    workgroup as the tile capacity allows; when that leaves too few row blocks to fill the chip (few rows, e.g. one
+    rank's shard), let several workgroups share a row block by splitting its panels into groups."""
     W = 1 << lw
+    P = max(1, (ncols + W - 1) // W)
     per_row_panel = max(nnz / max(nrows, 1) * min(W, ncols) / max(ncols, 1), 1e-9)   # mean items of a row in a panel
-    best, best_score = 2, -1.0
+    best, best_score = (2, 1), -1.0
     for rpt in range(2, RPT_MAX + 1, 2):
         rb = NT * rpt
         mean_tile = rb * per_row_panel
         if mean_tile + 6.0 * mean_tile ** 0.5 > cap and rpt > 2:      # keep 6 sigma below the LDS capacity
             break
         nblk = (nrows + rb - 1) // rb
-        rounds = (nblk + ncu - 1) // ncu
-        eff = nblk / (rounds * ncu)                                   # fill of the last round
-        score = eff * min(1.0, 0.35 + 0.65 * rpt / RPT_MAX)           # density matters, a ragged round matters more
-        if score > best_score:
-            best, best_score = rpt, score
+        density = min(1.0, 0.35 + 0.65 * rpt / RPT_MAX)
+        for groups in range(1, min(max_groups, P) + 1):
+            blocks = nblk * groups
+            rounds = (blocks + slots - 1) // slots
+            eff = blocks / (rounds * slots)                           # fill of the last round of workgroups
+            score = eff * density * (1.0 if groups == 1 else 0.97)   # split tiles pay a small epilogue kernel
+            if score > best_score:
+                best, best_score = (rpt, groups), score
     return best
 
 
+def choose_rpt(nrows: int, nnz: int, ncols: int, lw: int, cap: int = CAP, ncu: int = NCU) -> int:
+    return choose_shape(nrows, nnz, ncols, lw, cap, ncu)[0]
+
+
 def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, nrows: int, ncols: int,
-                lw: int = LW_DEFAULT, rpt: Optional[int] = None, cap: int = CAP, max_chunk_nnz: int = 1 << 26) -> Optional[Tiles]:
+                lw: int = LW_DEFAULT, rpt: Optional[int] = None, cap: int = CAP, max_chunk_nnz: int = 1 << 26,
+                groups: Optional[int] = None) -> Optional[Tiles]:
     """CSR (any row lengths, columns sorted or not) -> Tiles, or None when not eligible.  Runs on the
     tensors' device with torch sorts (setup cost, done once per matrix)."""
     dev = val.device
@@ -102,7 +113,9 @@ def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, n
     nnz = int(colidx.numel())
     W = 1 << lw
     if rpt is None:
-        rpt = choose_rpt(nrows, nnz, ncols, lw, cap)
+        rpt, g_auto = choose_shape(nrows, nnz, ncols, lw, cap)
+        groups = g_auto if groups is None else groups
+    groups = 1 if groups is None else int(groups)
     if rpt % 2 or not 2 <= rpt <= RPT_MAX:
         raise ValueError("rpt must be even and <= 40")
     RB = NT * rpt
@@ -183,7 +196,7 @@ def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, n
         b_lo = b_hi
     tile_ptr[NB * P] = base
     return Tiles(lw, rpt, cap, NB, P, nrows, ncols, out_idx[:base].contiguous(), out_val[:base].contiguous(),
-                 tile_ptr.to(torch.int32), cnt)
+                 tile_ptr.to(torch.int32), cnt, max(1, min(groups, P, 8)))
 
 
 def tile_row_counts(t: Tiles, tile: int) -> torch.Tensor:
