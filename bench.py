@@ -131,12 +131,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("PDLP_DIST_BACKEND", "nccl")       # "gloo" + PDLP_BENCH_SHARE_GPU=1: rehearsal on a 1-GPU box
+    if os.environ.get("PDLP_BENCH_SHARE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     comm = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
         comm = tp.Comm()
     m = args.m or args.n
     dt = torch.float32 if args.dtype == "f32" else torch.float64

@@ -513,3 +513,47 @@ def test_tiled_engine_steps_and_kkt_match_csr_engine(monkeypatch):
     x, obj, k, n, j, status, _ = tp.pdlp_algorithm(K, lp.m_ineq, lp.c, lp.q, lp.l, lp.u, DEV, verbose=False, adaptive=True,
                                                    primal_update=True, seed=0)
     assert status == "Solved" and abs(obj - lp.opt_obj) <= 2e-3 * (1 + abs(lp.opt_obj))
+
+
+def test_neos3_shaped_instance_matches_oracle():
+    """BASELINE.json configs[2] names Mittelmann's neos3 (512 209 x 6 624, 1.54M non-zeros); the file is not
+    available offline, so this is a synthetic of the same shape and skew: ~3 non-zeros per row of K, columns
+    drawn from a heavy-tailed distribution so K' has rows from a handful to tens of thousands of entries
+    (the CSR kernel's whole-workgroup path)."""
+    rng = np.random.default_rng(8)
+    m, n, nnz = 512_209, 6_624, 1_542_816
+    w = rng.pareto(1.1, n) + 0.05
+    cols = rng.choice(n, size=nnz, p=w / w.sum())
+    rows = np.sort(rng.integers(0, m, size=nnz))
+    key = np.unique(rows.astype(np.int64) * n + cols)
+    rows, cols = (key // n).astype(np.int64), (key % n).astype(np.int32)
+    rp = np.zeros(m + 1, np.int32)
+    rp[1:] = np.cumsum(np.bincount(rows, minlength=m))
+    va = rng.standard_normal(len(cols)).astype(np.float32)
+    m_ineq = m // 2
+    c = rng.standard_normal(n).astype(np.float32)
+    q = rng.standard_normal(m).astype(np.float32) * 0.1
+    l, u = np.zeros(n, np.float32), np.full(n, np.inf, np.float32)
+    u[::3] = 5.0
+    o = orc.OracleLP(m, n, m_ineq, rp, cols, va, c, q, l, u)
+    assert int(np.diff(o.trp).max()) > 2048                        # some rows of K' exceed the LDS cap
+    K = tp.CsrPair(m, n, dev(rp, torch.int32), dev(cols, torch.int32), dev(va))
+    eng = tp.PdlpEngine.from_full(K, dev(c), dev(q), dev(l), dev(u), m_ineq)
+    x0 = np.abs(rng.standard_normal(n)).astype(np.float32)
+    y0 = rng.standard_normal(m).astype(np.float32)
+    y0[:m_ineq] = np.abs(y0[:m_ineq])
+    sigma = eng.power_iteration(dev(rng.standard_normal(n).astype(np.float32)), 30)
+    eta, om = np.float32(0.9 / sigma), np.float32(1.0)
+    eng.set_iterate(dev(x0), dev(y0))
+    eng.set_step(float(eta), float(om), 1.0, 0)
+    eng.iterate(5, True)
+    xo, yo, e = x0, y0, eta
+    for k in range(1, 6):
+        xo, yo, _, e, _ = o.step_adaptive(xo, yo, e, om, 1.0, k)
+    x, y = eng.get_iterate(N.CUR)
+    close(x, xo, 5e-5)
+    close(y, yo, 5e-5)
+    np.testing.assert_allclose(eng.scalars()["eta"], float(e), rtol=2e-4)
+    got, ref = eng.kkt(N.CUR, 1.0), o.kkt(xo, yo, om)
+    for key in ("pr", "dr", "p", "d_adj", "kkt"):
+        np.testing.assert_allclose(got[key], float(ref[key]), rtol=2e-4, atol=1e-3)

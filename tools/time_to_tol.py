@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Time-to-tolerance on the bench LP (BASELINE.json metric, second half): full restarted solve, prints the
+restart log every check.  python tools/time_to_tol.py [n] [nnz_per_row] [tol] [ruiz 0/1] [max_kkt]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torchpdlp_amd as tp
+from torchpdlp_amd.solver import run_pdlp
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+tol = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-4
+ruiz = len(sys.argv) > 4 and sys.argv[4] == "1"
+max_kkt = int(sys.argv[5]) if len(sys.argv) > 5 else 40000
+dev = torch.device("cuda", 0)
+t0 = time.time()
+lp = tp.gen_lp(n, n, k, seed=0, device=dev)
+K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
+c, q, l, u = lp.c, lp.q, lp.l, lp.u
+dcol = drow = None
+t_ruiz = 0.0
+if ruiz:
+    K, c, q, l, u, dp, t_ruiz = tp.ruiz_precondition(c, K, q, l, u, device=dev)
+    dcol, drow = dp[0], dp[1]
+eng = tp.PdlpEngine.from_full(K, c, q, l, u, lp.m_ineq, d_col=dcol, d_row=drow)
+torch.cuda.synchronize()
+print(f"setup {time.time()-t0:.1f}s (ruiz {t_ruiz:.2f}s) tiles={[t is not None for t in eng.tiles]}", flush=True)
+trace = dict(kkt=[], omega=[], restarts=[])
+x, obj, it, nr, j, status, secs = run_pdlp(eng, max_kkt=max_kkt, tol=tol, verbose=True, precondition=ruiz, primal_update=True,
+                                           adaptive=True, time_limit=900, seed=0, power_iters=100, trace=trace)
+print(f"RESULT n={n} k={k} tol={tol} ruiz={ruiz}: status={status} obj={obj:.6f} iterations={it} restarts={nr} kkt_passes={j} "
+      f"solve_time={secs:.2f}s  ({it/secs:.1f} it/s incl. power iteration and checks)", flush=True)
