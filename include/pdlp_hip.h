@@ -73,23 +73,24 @@ typedef struct pdlp_problem {
     void* stream;               /* hipStream_t all work is enqueued on (0 = null stream)                    */
 } pdlp_problem;
 
-/* Optional panel-tiled copy of one of the two matrices (float32; layout and builder: torchpdlp_amd/tiled.py).
+/* Optional panel-tiled copy of one of the two matrices (layout and builder: torchpdlp_amd/tiled.py).
  * Rows are cut into blocks of 512*rpt rows (one workgroup each; thread t owns rows t*rpt .. t*rpt+rpt-1 of
  * the block), columns into panels of 2^lw entries; a tile is (row block, panel).  Items of a tile are sorted
  * by column; item = value + ((slot << lw) | local column), slot = rank of the item in row order inside the
  * tile; tiles are padded to multiples of 256 items with (value 0, slot = number of real items, column 0), and
  * every group of 256 sorted items is stored interleaved (position 4*lane + j holds sorted item 64*j + lane) so
- * that one wave's j-th gathers are 64 consecutive sorted items.  cnt holds, per (tile, thread), five 32-bit
- * words = 40 nibbles: the item counts (<= 15) of the thread's rows. */
+ * that one wave's j-th gathers are 64 consecutive sorted items.  cnt holds, per (tile, thread), five (float32) or
+ * three (float64) 32-bit words of 4-bit item counts (<= 15) of the thread's rows.  float32: rpt <= 40,
+ * cap <= 16384; float64: rpt <= 24, cap <= 8192. */
 typedef struct pdlp_tiles {
-    int32_t lw, rpt, cap;       /* panel = 2^lw columns; rows per thread (even, <= 40); most items per tile  */
+    int32_t lw, rpt, cap;       /* panel = 2^lw columns; rows per thread (even)       ; most items per tile  */
     int32_t nblk, npanel;       /* row blocks, column panels                                               */
     int32_t groups;             /* workgroups sharing a row block, each walking ceil(npanel/groups) panels; 1 = the
                                    epilogue is fused, > 1 (<= 8, <= npanel) = partial row sums + k_rowsum_epilogue */
     const uint32_t* idx;        /* [items]                                                                 */
-    const void* val;            /* [items] float32                                                         */
+    const void* val;            /* [items] in the problem's precision                                      */
     const int32_t* tile_ptr;    /* [nblk*npanel + 1] item offsets, multiples of 256                        */
-    const uint32_t* cnt;        /* [nblk*npanel*512*5]                                                     */
+    const uint32_t* cnt;        /* [nblk*npanel*512*(5|3)]                                                 */
 } pdlp_tiles;
 
 typedef struct pdlp_solver* pdlp_handle;

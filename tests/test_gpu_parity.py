@@ -557,3 +557,31 @@ def test_neos3_shaped_instance_matches_oracle():
     got, ref = eng.kkt(N.CUR, 1.0), o.kkt(xo, yo, om)
     for key in ("pr", "dr", "p", "d_adj", "kkt"):
         np.testing.assert_allclose(got[key], float(ref[key]), rtol=2e-4, atol=1e-3)
+
+
+def test_tiled_float64_matches_csr_float64(monkeypatch):
+    """the float64 instantiation of the tiled kernel (8192-item tiles, 24 rows per thread) vs the CSR kernel"""
+    lp = gen_lp(300_000, 250_000, 3, seed=6, device=DEV, recipe="mixed", dtype=torch.float64)
+    K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
+    monkeypatch.setenv("PDLP_TILED", "0")
+    e0 = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
+    monkeypatch.setenv("PDLP_TILED", "1")
+    e1 = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
+    assert all(t is not None and t.val.dtype == torch.float64 and t.cw == 3 for t in e1.tiles)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    x0 = torch.minimum(torch.maximum(torch.randn(lp.n, device=DEV, generator=g, dtype=torch.float64), lp.l), lp.u)
+    y0 = torch.randn(lp.m, device=DEV, generator=g, dtype=torch.float64)
+    y0[:lp.m_ineq].clamp_(min=0)
+    outs = []
+    for e in (e0, e1):
+        e.set_iterate(x0, y0)
+        e.set_step(0.05, 1.2, 1.0, 0)
+        e.iterate(9, True)
+        x, y = e.get_iterate(N.CUR)
+        outs.append((x, y, e.scalars()["eta"], e.kkt(N.CUR, 1.2)))
+    (xa, ya, ea, ka), (xb, yb, eb, kb) = outs
+    close(xb, xa.cpu().numpy(), 1e-11)
+    close(yb, ya.cpu().numpy(), 1e-11)
+    np.testing.assert_allclose(eb, ea, rtol=1e-10)
+    for key in ("pr", "dr", "gap", "p", "d_adj", "kkt"):
+        np.testing.assert_allclose(kb[key], ka[key], rtol=1e-9, atol=1e-9)

@@ -65,7 +65,12 @@ def test_not_eligible_when_a_tile_or_a_row_is_too_full():
     assert build_tiles(rp, ci, va, 640, 64, lw=6, rpt=2, cap=8000) is not None
     rp, ci, va = _csr(4, 600, np.array([30, 1, 1, 1]), 4)
     assert build_tiles(rp, ci, va, 4, 600, lw=10, rpt=2, cap=2000) is None        # 16+ entries of one row in one panel
-    assert build_tiles(rp, ci, va.double(), 4, 600, lw=4, rpt=2) is None           # float32 only
+    t64 = build_tiles(rp, ci, va.double(), 4, 600, lw=6, rpt=2)                     # float64: 3 count words, 8192-item tiles
+    assert t64 is not None and t64.cw == 3 and t64.cap == 8192 and t64.val.dtype == torch.float64
+    x = torch.arange(600, dtype=torch.float64)
+    ref = torch.zeros(4, dtype=torch.float64).index_add_(0, torch.repeat_interleave(torch.arange(4), torch.tensor([30, 1, 1, 1])),
+                                                          va.double() * x[ci.long()])
+    np.testing.assert_allclose(emulate_spmv(t64, x).numpy(), ref.numpy(), rtol=1e-12)
 
 
 def test_choose_rpt_fills_whole_rounds():

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time-to-tolerance on the bench LP (BASELINE.json metric, second half): full restarted solve, prints the
-restart log every check.  python tools/time_to_tol.py [n] [nnz_per_row] [tol] [ruiz 0/1] [max_kkt]"""
+restart log every check.  python tools/time_to_tol.py [n] [nnz_per_row] [tol] [ruiz 0/1] [max_kkt] [f32|f64]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,9 +12,10 @@ k = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 tol = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-4
 ruiz = len(sys.argv) > 4 and sys.argv[4] == "1"
 max_kkt = int(sys.argv[5]) if len(sys.argv) > 5 else 40000
+dt = torch.float64 if (len(sys.argv) > 6 and sys.argv[6] == "f64") else torch.float32
 dev = torch.device("cuda", 0)
 t0 = time.time()
-lp = tp.gen_lp(n, n, k, seed=0, device=dev)
+lp = tp.gen_lp(n, n, k, seed=0, device=dev, dtype=dt)
 K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
 c, q, l, u = lp.c, lp.q, lp.l, lp.u
 dcol = drow = None
@@ -28,5 +29,5 @@ print(f"setup {time.time()-t0:.1f}s (ruiz {t_ruiz:.2f}s) tiles={[t is not None f
 trace = dict(kkt=[], omega=[], restarts=[])
 x, obj, it, nr, j, status, secs = run_pdlp(eng, max_kkt=max_kkt, tol=tol, verbose=True, precondition=ruiz, primal_update=True,
                                            adaptive=True, time_limit=900, seed=0, power_iters=100, trace=trace)
-print(f"RESULT n={n} k={k} tol={tol} ruiz={ruiz}: status={status} obj={obj:.6f} iterations={it} restarts={nr} kkt_passes={j} "
+print(f"RESULT n={n} k={k} tol={tol} ruiz={ruiz} dtype={dt}: status={status} obj={obj:.6f} iterations={it} restarts={nr} kkt_passes={j} "
       f"solve_time={secs:.2f}s  ({it/secs:.1f} it/s incl. power iteration and checks)", flush=True)

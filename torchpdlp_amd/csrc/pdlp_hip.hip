@@ -247,27 +247,31 @@ __global__ __launch_bounds__(BLOCK) void k_csr_fused(const int32_t* __restrict__
 // on consecutive rows (coalesced vector traffic).
 // ------------------------------------------------------------------------------------------------
 constexpr int TNT = 512;                 // threads per workgroup
-constexpr int TRPT_MAX = 40;             // most rows per thread
-constexpr int TCW = TRPT_MAX / 8;        // 32-bit words of 4-bit counts per thread and tile
-constexpr int TCAP = 16384;              // most items per tile
-constexpr int TU = 4;                    // 16-byte chunks per thread and register group
-constexpr int TGRP = TNT * 4 * TU;       // items per register group
-
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+// per precision: most rows per thread (a multiple of 8: one 32-bit word holds 8 counts), most items per tile
+// (64 KB of LDS products, two workgroups per CU), 4-item chunks per thread and register group
+template <typename T> struct TileCfg;
+template <> struct TileCfg<float> { static constexpr int RPT_MAX = 40, CAP = 16384, TU = 4; typedef f32x4 V4; };
+template <> struct TileCfg<double> { static constexpr int RPT_MAX = 24, CAP = 8192, TU = 2; typedef f64x4 V4; };
+constexpr int TRPT_MAX_ANY = 40;
 
 // FUSED: the workgroup walks ALL panels of its row block and runs the epilogue itself.  Otherwise the panels of
 // a row block are split over `groups` workgroups (blockIdx = group * nblk + row block; needed when there are too
 // few rows for one workgroup per row block to fill the chip, e.g. one rank's shard of a sharded problem): each
 // writes its partial row sums to rowsum[group] and k_rowsum_epilogue adds them in fixed order.
-template <class Epi, bool FUSED>
-__global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restrict__ tidx, const float* __restrict__ tval,
+template <typename T, class Epi, bool FUSED>
+__global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restrict__ tidx, const T* __restrict__ tval,
                                                         const int32_t* __restrict__ tile_ptr, const uint32_t* __restrict__ tcnt,
                                                         int npanel, int lw, int rpt, int nrows, int nblk, int ppg,
-                                                        const float* __restrict__ vin, float* __restrict__ rowsum,
+                                                        const T* __restrict__ vin, T* __restrict__ rowsum,
                                                         int64_t rs_stride, Epi epi, double* __restrict__ partials)
 {
-    __shared__ __attribute__((aligned(16))) float prod[TCAP + 8];
+    constexpr int TRPT_MAX = TileCfg<T>::RPT_MAX, TCW = TRPT_MAX / 8, TCAP = TileCfg<T>::CAP, TU = TileCfg<T>::TU;
+    constexpr int TGRP = TNT * 4 * TU;       // items per register group
+    typedef typename TileCfg<T>::V4 V4;
+    __shared__ __attribute__((aligned(16))) T prod[TCAP + 8];
     __shared__ int wsum[TNT / 64];
     __shared__ double dred8[TNT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -276,12 +280,12 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
     const int p_lo = grp * ppg, p_hi = (p_lo + ppg < npanel) ? p_lo + ppg : npanel;
     const uint32_t mask = (1u << lw) - 1u;
     if (FUSED) epi.load();
-    float acc[TRPT_MAX];
+    T acc[TRPT_MAX];
 #pragma unroll
-    for (int r = 0; r < TRPT_MAX; ++r) acc[r] = 0.0f;
+    for (int r = 0; r < TRPT_MAX; ++r) acc[r] = (T)0;
 
     u32x4 pk[TU];
-    f32x4 vv[TU];
+    V4 vv[TU];
     const uint32_t trash = (uint32_t)TCAP << lw;       // slot TCAP (past every real slot), column 0
     // the item stream is read once: non-temporal loads keep it from evicting the gathered panel out of the L2
     auto load_group = [&](int g0, int i1) {
@@ -291,14 +295,14 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
             if (i < i1) {
 #ifdef PDLP_TEMPORAL_STREAM
                 pk[u] = *reinterpret_cast<const u32x4*>(tidx + i);
-                vv[u] = *reinterpret_cast<const f32x4*>(tval + i);
+                vv[u] = *reinterpret_cast<const V4*>(tval + i);
 #else
                 pk[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(tidx + i));
-                vv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(tval + i));
+                vv[u] = __builtin_nontemporal_load(reinterpret_cast<const V4*>(tval + i));
 #endif
             } else {
                 pk[u] = u32x4{trash, trash, trash, trash};
-                vv[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                vv[u] = V4{(T)0, (T)0, (T)0, (T)0};
             }
         }
     };
@@ -309,7 +313,7 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
 
     for (int p = p_lo; p < p_hi; ++p) {
         const size_t tile = tile0 + p;
-        const float* __restrict__ xin = vin + ((size_t)p << lw);
+        const T* __restrict__ xin = vin + ((size_t)p << lw);
         const int i0n = i1, i1n = p + 1 < p_hi ? tile_ptr[tile + 2] : i1;       // the next tile (empty after the last)
         // segment lengths of this thread's rows (4 bits each) and their offset inside the wave
         uint32_t cw[TCW];
@@ -331,11 +335,11 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
         // pass 1, one register group at a time; the next group (of this tile or of the next) is loaded as soon as
         // the current one is consumed
         for (int g0 = i0; g0 < i1; g0 += TGRP) {
-            float xg[TU * 4];
+            T xg[TU * 4];
 #pragma unroll
             for (int u = 0; u < TU; ++u) {
 #ifdef PDLP_ABL_NOGATHER
-                xg[4 * u + 0] = xg[4 * u + 1] = xg[4 * u + 2] = xg[4 * u + 3] = (float)(pk[u].x & 1u);
+                xg[4 * u + 0] = xg[4 * u + 1] = xg[4 * u + 2] = xg[4 * u + 3] = (T)(pk[u].x & 1u);
 #else
                 xg[4 * u + 0] = xin[pk[u].x & mask];
                 xg[4 * u + 1] = xin[pk[u].y & mask];
@@ -365,14 +369,14 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
         for (int r = 0; r < TRPT_MAX; ++r) {
             if (r < rpt) {
                 const int c = (int)((cw[r >> 3] >> ((r & 7) * 4)) & 0xfu);
-                float s = 0.0f;
+                T s = (T)0;
                 for (int k = 0; k < c; ++k) s += prod[start + k];
                 start += c;
                 acc[r] += s;
             }
         }
 #else
-        acc[1] += (float)(start + (int)cw[0]);
+        acc[1] += (T)(start + (int)cw[0]);
 #endif
         __syncthreads();
         i0 = i0n;
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
     // per row, L2 resident) so that the epilogue runs with consecutive lanes on consecutive rows and all of
     // its vector traffic is coalesced.  (The 512*40 sums do not fit the 64 KB product buffer.)
     const int rb = TNT * rpt;
-    float* __restrict__ rs = rowsum + (size_t)grp * rs_stride + (size_t)b * rb;
+    T* __restrict__ rs = rowsum + (size_t)grp * rs_stride + (size_t)b * rb;
 #pragma unroll
     for (int r = 0; r < TRPT_MAX; ++r)
         if (r < rpt) rs[tid * rpt + r] = acc[r];
@@ -415,15 +419,15 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
 }
 
 // epilogue of the split tiled kernel: row sum = sum over panel groups (fixed order), then the fused vector update
-template <class Epi>
-__global__ __launch_bounds__(BLOCK) void k_rowsum_epilogue(const float* __restrict__ rowsum, int groups, int64_t rs_stride,
+template <typename T, class Epi>
+__global__ __launch_bounds__(BLOCK) void k_rowsum_epilogue(const T* __restrict__ rowsum, int groups, int64_t rs_stride,
                                                            int nrows, Epi epi, double* __restrict__ partials)
 {
     __shared__ double dred[4];
     epi.load();
     double acc[NACC] = {0.0, 0.0, 0.0, 0.0};
     for (int row = blockIdx.x * BLOCK + threadIdx.x; row < nrows; row += gridDim.x * BLOCK) {
-        float s = __builtin_nontemporal_load(rowsum + row);
+        T s = __builtin_nontemporal_load(rowsum + row);
         for (int g = 1; g < groups; ++g) s += __builtin_nontemporal_load(rowsum + (size_t)g * rs_stride + row);
         epi(row, s, acc);
     }
@@ -721,7 +725,7 @@ struct pdlp_solver {
     char* kxb[3];                 // K x caches: [0] running, [1] from KKT(cur), [2] from KKT(avg)
     bool kx_valid, cand_valid[2];
     double *partA, *partB, *red, *sc;
-    float* rowsum;                // row sums of the tiled kernel on their way to the epilogue: [groups][rs_stride]
+    void* rowsum;                 // row sums of the tiled kernel on their way to the epilogue: [groups][rs_stride]
     int64_t rs_stride;            // rows + one row block
     int rs_groups;                // panel groups the scratch has room for
     int last_gridA, last_gridB;   // grids of the last primal / dual launch (adaptive reduce)
@@ -734,19 +738,19 @@ int launch_csr(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* 
 {
     const Schedule& s = transpose ? h->sKT : h->sK;
     if (s.nblk == 0) return PDLP_OK;
-    if constexpr (sizeof(T) == 4) if (s.tiled) {
+    if (s.tiled) {
         const int rows = (int)(transpose ? h->nl : h->ml);
         const int ppg = (s.t.npanel + s.t.groups - 1) / s.t.groups;
         if (s.t.groups == 1) {
-            hipLaunchKernelGGL((k_tiled_fused<Epi, true>), dim3(s.t.nblk), dim3(TNT), 0, h->stream, s.t.idx, (const float*)s.t.val,
-                               s.t.tile_ptr, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, ppg, (const float*)vin,
-                               h->rowsum, h->rs_stride, epi, partials);
+            hipLaunchKernelGGL((k_tiled_fused<T, Epi, true>), dim3(s.t.nblk), dim3(TNT), 0, h->stream, s.t.idx, (const T*)s.t.val,
+                               s.t.tile_ptr, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, ppg, (const T*)vin,
+                               (T*)h->rowsum, h->rs_stride, epi, partials);
         } else {
-            hipLaunchKernelGGL((k_tiled_fused<Epi, false>), dim3(s.t.nblk * s.t.groups), dim3(TNT), 0, h->stream, s.t.idx,
-                               (const float*)s.t.val, s.t.tile_ptr, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, ppg,
-                               (const float*)vin, h->rowsum, h->rs_stride, epi, partials);
-            hipLaunchKernelGGL((k_rowsum_epilogue<Epi>), dim3(grid_for(rows)), dim3(BLOCK), 0, h->stream, h->rowsum, s.t.groups,
-                               h->rs_stride, rows, epi, partials);
+            hipLaunchKernelGGL((k_tiled_fused<T, Epi, false>), dim3(s.t.nblk * s.t.groups), dim3(TNT), 0, h->stream, s.t.idx,
+                               (const T*)s.t.val, s.t.tile_ptr, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, ppg,
+                               (const T*)vin, (T*)h->rowsum, h->rs_stride, epi, partials);
+            hipLaunchKernelGGL((k_rowsum_epilogue<T, Epi>), dim3(grid_for(rows)), dim3(BLOCK), 0, h->stream, (const T*)h->rowsum,
+                               s.t.groups, h->rs_stride, rows, epi, partials);
         }
         HIP_TRY(hipGetLastError());
         return PDLP_OK;
@@ -931,7 +935,7 @@ int check_problem(const pdlp_problem* p)
 
 // panel groups the row-sum scratch is sized for: splitting only pays when one workgroup per (largest) row block
 // cannot fill 2 x 256 CUs, i.e. below about 10.5M rows
-inline int64_t rowsum_groups(int64_t rows) { return rows <= (int64_t)TNT * TRPT_MAX * 512 ? 8 : 1; }
+inline int64_t rowsum_groups(int64_t rows) { return rows <= (int64_t)TNT * TRPT_MAX_ANY * 512 ? 8 : 1; }
 
 struct Carve {
     int64_t off = 0;
@@ -960,7 +964,7 @@ int64_t layout(const pdlp_problem* p, int64_t nnzK, int64_t nnzKT, int64_t* offs
     offs[k++] = c.take(PDLP_NSCAL * 8);                           // 17    sc
     offs[k++] = c.take((max_blocks(ml, nnzK) + 1) * 4);           // 18    schedule K
     offs[k++] = c.take((max_blocks(nl, nnzKT) + 1) * 4);          // 19    schedule K'
-    offs[k++] = c.take(rowsum_groups(nl > ml ? nl : ml) * ((nl > ml ? nl : ml) + (int64_t)TNT * TRPT_MAX) * 4);   // 20  rowsum scratch
+    offs[k++] = c.take(rowsum_groups(nl > ml ? nl : ml) * ((nl > ml ? nl : ml) + (int64_t)TNT * TRPT_MAX_ANY) * es);   // 20  rowsum scratch
     return c.off;
 }
 
@@ -1039,8 +1043,8 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     h->partA = (double*)(w + offs[14]); h->partB = (double*)(w + offs[15]);
     h->red = (double*)(w + offs[16]); h->sc = (double*)(w + offs[17]);
     h->sK.blk = (int32_t*)(w + offs[18]); h->sKT.blk = (int32_t*)(w + offs[19]);
-    h->rowsum = (float*)(w + offs[20]);
-    h->rs_stride = (nl > ml ? nl : ml) + (int64_t)TNT * TRPT_MAX;
+    h->rowsum = (void*)(w + offs[20]);
+    h->rs_stride = (nl > ml ? nl : ml) + (int64_t)TNT * TRPT_MAX_ANY;
     h->rs_groups = (int)rowsum_groups(nl > ml ? nl : ml);
     h->kx_valid = false; h->cand_valid[0] = h->cand_valid[1] = false;
     h->last_gridA = h->last_gridB = 0;
@@ -1096,9 +1100,10 @@ int pdlp_attach_tiles(pdlp_handle h, int transpose, const pdlp_tiles* t)
     if (!h) return PDLP_ERR_INVALID;
     Schedule& s = transpose ? h->sKT : h->sK;
     if (!t) { s.tiled = false; return PDLP_OK; }
-    if (h->p.dtype != PDLP_F32) return PDLP_ERR_INVALID;          // the tiled kernel is float32 only
     const int64_t rows = transpose ? h->nl : h->ml;
-    if (t->rpt < 2 || t->rpt > TRPT_MAX || (t->rpt & 1) || t->cap > TCAP || t->lw < 4 || t->lw > 16) return PDLP_ERR_INVALID;
+    const int rpt_max = h->p.dtype == PDLP_F32 ? TileCfg<float>::RPT_MAX : TileCfg<double>::RPT_MAX;
+    const int cap_max = h->p.dtype == PDLP_F32 ? TileCfg<float>::CAP : TileCfg<double>::CAP;
+    if (t->rpt < 2 || t->rpt > rpt_max || (t->rpt & 1) || t->cap > cap_max || t->lw < 4 || t->lw > 16) return PDLP_ERR_INVALID;
     const int64_t rb = (int64_t)TNT * t->rpt;
     if (t->nblk != (int)((rows + rb - 1) / rb) || t->npanel < 1) return PDLP_ERR_INVALID;
     if (t->groups < 1 || t->groups > h->rs_groups || t->groups > t->npanel) return PDLP_ERR_INVALID;

@@ -110,7 +110,7 @@ class PdlpEngine:
         if mode == "0":
             return
         for transpose, (rp, ci, va), rows, cols in ((0, self.K, self.ml, self.n), (1, self.KT, self.nl, self.m)):
-            if rows == 0 or self.dtype != torch.float32 or (mode != "1" and cols < (1 << 20)):
+            if rows == 0 or (mode != "1" and cols < (1 << 20)):
                 continue
             t = _tiled.build_tiles(rp, ci, va, rows, cols)
             if t is None:

@@ -22,8 +22,8 @@ instruction j covers 64 CONSECUTIVE sorted items (about 25 lines at 100 non-zero
 spaced four apart (64 lines).  Bytes per non-zero: 8 + 20*512*P/nnz_per_block (the count nibbles): about 8.9 for 100 non-zeros per row at
 10M columns.
 
-A matrix is eligible when it is float32, every tile holds at most ``cap`` items and no (tile, row) more than
-15; otherwise ``build_tiles`` returns None and the CSR kernel is used.
+A matrix is eligible when every tile holds at most ``cap`` items (16384 in float32, 8192 in float64) and no
+(tile, row) more than 15; otherwise ``build_tiles`` returns None and the CSR kernel is used.
 """
 from __future__ import annotations
 
@@ -34,9 +34,10 @@ import torch
 
 LW_DEFAULT = 16      # panel = 65536 columns (256 KB of f32: L2 resident on every XCD)
 NT = 512             # threads per workgroup (fixed by the kernel)
-RPT_MAX = 40         # most rows per thread
-CW = RPT_MAX // 8    # 32-bit words of 4-bit counts per (tile, thread)
-CAP = 16384          # items per tile each of the kernel's two LDS product buffers holds
+RPT_MAX = 40         # float32: most rows per thread; 32-bit words of 4-bit counts per (tile, thread) = RPT_MAX/8
+CAP = 16384          # float32: items per tile (64 KB of LDS products per workgroup)
+RPT_MAX_F64 = 24     # float64: the same LDS and register budget holds half as many
+CAP_F64 = 8192
 GROUP = 256          # tiles are padded to whole groups of 4 x 64 items (interleaved, see above)
 NCU = 512            # two workgroups per CU at a time: row blocks are sized to fill whole rounds
 
@@ -53,8 +54,13 @@ class Tiles:
     idx: torch.Tensor        # int32 [items]  (slot << lw) | local column
     val: torch.Tensor        # float32 [items]
     tile_ptr: torch.Tensor   # int32 [nblk*npanel + 1], item offsets, multiples of 256
-    cnt: torch.Tensor        # int32 [nblk*npanel*512*5]: 40 nibbles per (tile, thread)
+    cnt: torch.Tensor        # int32 [nblk*npanel*512*cw]: 8*cw nibbles per (tile, thread); cw = 5 (f32) or 3 (f64)
     groups: int = 1          # workgroups sharing a row block (each walks ceil(npanel/groups) panels)
+    rpt_max: int = RPT_MAX   # rows per thread the kernel instantiation for this precision supports
+
+    @property
+    def cw(self) -> int:
+        return self.rpt_max // 8
 
     @property
     def items(self) -> int:
@@ -73,7 +79,13 @@ def _wrap_i32(v: torch.Tensor) -> torch.Tensor:
     return torch.where(v >= 2 ** 31, v - 2 ** 32, v).to(torch.int32)
 
 
-def choose_shape(nrows: int, nnz: int, ncols: int, lw: int, cap: int = CAP, slots: int = NCU, max_groups: int = 8):
+def limits(dtype):
+    """(most rows per thread, most items per tile) of the kernel instantiation for ``dtype``"""
+    return (RPT_MAX, CAP) if dtype == torch.float32 else (RPT_MAX_F64, CAP_F64)
+
+
+def choose_shape(nrows: int, nnz: int, ncols: int, lw: int, cap: int = CAP, slots: int = NCU, max_groups: int = 8,
+                 rpt_max: int = RPT_MAX):
     """(rows per thread, panel groups).  Denser tiles mean fewer cache lines per gather, so take as many rows per
     workgroup as the tile capacity allows; when that leaves too few row blocks to fill the chip (few rows, e.g. one
     rank's shard), let several workgroups share a row block by splitting its panels into groups."""
@@ -81,13 +93,13 @@ def choose_shape(nrows: int, nnz: int, ncols: int, lw: int, cap: int = CAP, slot
     P = max(1, (ncols + W - 1) // W)
     per_row_panel = max(nnz / max(nrows, 1) * min(W, ncols) / max(ncols, 1), 1e-9)   # mean items of a row in a panel
     best, best_score = (2, 1), -1.0
-    for rpt in range(2, RPT_MAX + 1, 2):
+    for rpt in range(2, rpt_max + 1, 2):
         rb = NT * rpt
         mean_tile = rb * per_row_panel
         if mean_tile + 6.0 * mean_tile ** 0.5 > cap and rpt > 2:      # keep 6 sigma below the LDS capacity
             break
         nblk = (nrows + rb - 1) // rb
-        density = min(1.0, 0.35 + 0.65 * rpt / RPT_MAX)
+        density = min(1.0, 0.35 + 0.65 * rpt / rpt_max)
         for groups in range(1, min(max_groups, P) + 1):
             blocks = nblk * groups
             rounds = (blocks + slots - 1) // slots
@@ -103,25 +115,28 @@ def choose_rpt(nrows: int, nnz: int, ncols: int, lw: int, cap: int = CAP, ncu: i
 
 
 def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, nrows: int, ncols: int,
-                lw: int = LW_DEFAULT, rpt: Optional[int] = None, cap: int = CAP, max_chunk_nnz: int = 1 << 26,
+                lw: int = LW_DEFAULT, rpt: Optional[int] = None, cap: Optional[int] = None, max_chunk_nnz: int = 1 << 26,
                 groups: Optional[int] = None) -> Optional[Tiles]:
     """CSR (any row lengths, columns sorted or not) -> Tiles, or None when not eligible.  Runs on the
     tensors' device with torch sorts (setup cost, done once per matrix)."""
     dev = val.device
-    if val.dtype != torch.float32:
+    if val.dtype not in (torch.float32, torch.float64):
         return None
+    rpt_max, cap_max = limits(val.dtype)
+    cap = cap_max if cap is None else cap
+    CW = rpt_max // 8
     nnz = int(colidx.numel())
     W = 1 << lw
     if rpt is None:
-        rpt, g_auto = choose_shape(nrows, nnz, ncols, lw, cap)
+        rpt, g_auto = choose_shape(nrows, nnz, ncols, lw, cap, rpt_max=rpt_max)
         groups = g_auto if groups is None else groups
     groups = 1 if groups is None else int(groups)
-    if rpt % 2 or not 2 <= rpt <= RPT_MAX:
-        raise ValueError("rpt must be even and <= 40")
+    if rpt % 2 or not 2 <= rpt <= rpt_max:
+        raise ValueError(f"rpt must be even and <= {rpt_max}")
     RB = NT * rpt
     P = max(1, (ncols + W - 1) // W)
     NB = max(1, (nrows + RB - 1) // RB)
-    if cap + 4 > (1 << (32 - lw)) or cap > CAP:
+    if cap + 4 > (1 << (32 - lw)) or cap > cap_max:
         raise ValueError("cap does not fit")
     if nnz + GROUP * NB * P >= 2 ** 31:
         return None
@@ -158,7 +173,7 @@ def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, n
             c_tr = torch.bincount(tile * RB + (rloc - rblk * RB), minlength=ntl * RB)
             if int(c_tr.max()) > 15:
                 return None
-            nib = torch.zeros(ntl, NT, RPT_MAX, dtype=torch.int64, device=dev)     # CW words = 40 nibbles per thread
+            nib = torch.zeros(ntl, NT, rpt_max, dtype=torch.int64, device=dev)     # CW words of 8 nibbles per thread
             nib[:, :, :rpt] = c_tr.view(ntl, NT, rpt)
             del c_tr
             words = (nib.view(ntl, NT, CW, 8) << shifts).sum(-1)
@@ -196,15 +211,16 @@ def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, n
         b_lo = b_hi
     tile_ptr[NB * P] = base
     return Tiles(lw, rpt, cap, NB, P, nrows, ncols, out_idx[:base].contiguous(), out_val[:base].contiguous(),
-                 tile_ptr.to(torch.int32), cnt, max(1, min(groups, P, 8)))
+                 tile_ptr.to(torch.int32), cnt, max(1, min(groups, P, 8)), rpt_max)
 
 
 def tile_row_counts(t: Tiles, tile: int) -> torch.Tensor:
     """items of each of the tile's 1024*rpt rows (unpacks the nibbles)"""
+    CW = t.cw
     w = t.cnt[tile * NT * CW:(tile + 1) * NT * CW].long() & 0xFFFFFFFF
     shifts = (torch.arange(8, device=w.device) * 4).view(1, 1, 8)
     nib = (w.view(NT, CW, 1) >> shifts) & 15
-    return nib.reshape(NT, RPT_MAX)[:, :t.rpt].reshape(-1)
+    return nib.reshape(NT, t.rpt_max)[:, :t.rpt].reshape(-1)
 
 
 def emulate_spmv(t: Tiles, x: torch.Tensor) -> torch.Tensor:
