@@ -112,9 +112,14 @@ class PdhgDriver:
         eng.compute_average()                                               # pdhg.py:118-119
         r_cur = eng.kkt(N.CUR, self.omega)                                  # pdhg.py:122-125
         r_avg = eng.kkt(N.AVG, self.omega)
-        r_prev = eng.kkt(N.PREV, self.omega)
-        k_cur, k_avg, k_prev = t(r_cur["kkt"]), t(r_avg["kkt"]), t(r_prev["kkt"])
+        k_cur, k_avg = t(r_cur["kkt"]), t(r_avg["kkt"])
         k_min = min(k_cur, k_avg)
+        # KKT_previous only enters the "necessary" test (pdhg.py:135); the reference evaluates it at every check.
+        # Here it is evaluated when that test can fire (or when a trace is recorded); the decision and the pass
+        # counter j are the same either way.
+        need_prev = self.trace is not None or (not k_min <= t(self.beta[0]) * self.KKT_first
+                                               and k_min <= t(self.beta[1]) * self.KKT_first)
+        k_prev = t(eng.kkt(N.PREV, self.omega)["kkt"]) if need_prev else t(np.inf)
         self.j += 3                                                         # pdhg.py:128
         if self.trace is not None:
             self.trace["kkt"] += [float(k_cur), float(k_avg), float(k_prev)]
