@@ -253,7 +253,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // per precision: most rows per thread (a multiple of 8: one 32-bit word holds 8 counts), most items per tile
 // (64 KB of LDS products, two workgroups per CU), 4-item chunks per thread and register group
 template <typename T> struct TileCfg;
-template <> struct TileCfg<float> { static constexpr int RPT_MAX = 40, CAP = 16384, TU = 4; typedef f32x4 V4; };
+template <> struct TileCfg<float> { static constexpr int RPT_MAX = 40, CAP = 16384, TU = 3; typedef f32x4 V4; };
 template <> struct TileCfg<double> { static constexpr int RPT_MAX = 24, CAP = 8192, TU = 2; typedef f64x4 V4; };
 constexpr int TRPT_MAX_ANY = 40;
 
