@@ -5,7 +5,7 @@ import pytest
 import scipy.sparse as sp
 import torch
 
-from torchpdlp_amd.tiled import NT, build_tiles, choose_rpt, choose_shape, emulate_spmv, tile_row_counts
+from torchpdlp_amd.tiled import NT, build_tiles, choose_rpt, choose_shape, emulate_spmv, normalize_groups, tile_row_counts
 
 
 def _csr(m, n, lens, seed):
@@ -71,6 +71,16 @@ def test_not_eligible_when_a_tile_or_a_row_is_too_full():
     ref = torch.zeros(4, dtype=torch.float64).index_add_(0, torch.repeat_interleave(torch.arange(4), torch.tensor([30, 1, 1, 1])),
                                                           va.double() * x[ci.long()])
     np.testing.assert_allclose(emulate_spmv(t64, x).numpy(), ref.numpy(), rtol=1e-12)
+
+
+def test_no_panel_group_is_empty():
+    # the kernel gives each group ceil(P/groups) panels; 10 panels in 8 groups would leave three groups empty
+    assert normalize_groups(8, 10) == 5 and normalize_groups(3, 10) == 3 and normalize_groups(8, 153) == 8
+    for P in range(1, 40):
+        for g in range(1, 12):
+            gg = normalize_groups(g, P)
+            ppg = -(-P // gg)
+            assert 1 <= gg <= min(8, P) and (gg - 1) * ppg < P <= gg * ppg
 
 
 def test_choose_rpt_fills_whole_rounds():

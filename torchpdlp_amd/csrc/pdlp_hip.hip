@@ -307,8 +307,9 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
         }
     };
     const size_t tile0 = (size_t)b * npanel;
-    int i0 = tile_ptr[tile0 + p_lo];
-    int i1 = tile_ptr[tile0 + p_lo + 1];
+    const bool has_panels = p_lo < npanel;             // (pdlp_attach_tiles rejects group counts that leave a group empty)
+    int i0 = has_panels ? tile_ptr[tile0 + p_lo] : 0;
+    int i1 = has_panels ? tile_ptr[tile0 + p_lo + 1] : 0;
     load_group(i0, i1);
 
     for (int p = p_lo; p < p_hi; ++p) {
@@ -1107,6 +1108,8 @@ int pdlp_attach_tiles(pdlp_handle h, int transpose, const pdlp_tiles* t)
     const int64_t rb = (int64_t)TNT * t->rpt;
     if (t->nblk != (int)((rows + rb - 1) / rb) || t->npanel < 1) return PDLP_ERR_INVALID;
     if (t->groups < 1 || t->groups > h->rs_groups || t->groups > t->npanel) return PDLP_ERR_INVALID;
+    const int ppg = (t->npanel + t->groups - 1) / t->groups;
+    if ((t->groups - 1) * ppg >= t->npanel) return PDLP_ERR_INVALID;     // every group must own at least one panel
     if (!t->idx || !t->val || !t->tile_ptr || !t->cnt) return PDLP_ERR_INVALID;
     if (((uintptr_t)t->idx & 15u) || ((uintptr_t)t->val & 15u) || ((uintptr_t)t->cnt & 3u)) return PDLP_ERR_INVALID;
     s.t = *t;

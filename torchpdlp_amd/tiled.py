@@ -101,6 +101,8 @@ def choose_shape(nrows: int, nnz: int, ncols: int, lw: int, cap: int = CAP, slot
         nblk = (nrows + rb - 1) // rb
         density = min(1.0, 0.35 + 0.65 * rpt / rpt_max)
         for groups in range(1, min(max_groups, P) + 1):
+            if normalize_groups(groups, P, max_groups) != groups:
+                continue
             blocks = nblk * groups
             rounds = (blocks + slots - 1) // slots
             eff = blocks / (rounds * slots)                           # fill of the last round of workgroups
@@ -108,6 +110,13 @@ def choose_shape(nrows: int, nnz: int, ncols: int, lw: int, cap: int = CAP, slot
             if score > best_score:
                 best, best_score = (rpt, groups), score
     return best
+
+
+def normalize_groups(groups: int, npanel: int, max_groups: int = 8) -> int:
+    """the kernel gives every group ceil(npanel/groups) panels: shrink the count until no group is empty"""
+    g = max(1, min(int(groups), npanel, max_groups))
+    ppg = -(-npanel // g)
+    return -(-npanel // ppg)
 
 
 def choose_rpt(nrows: int, nnz: int, ncols: int, lw: int, cap: int = CAP, ncu: int = NCU) -> int:
@@ -211,7 +220,7 @@ def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, n
         b_lo = b_hi
     tile_ptr[NB * P] = base
     return Tiles(lw, rpt, cap, NB, P, nrows, ncols, out_idx[:base].contiguous(), out_val[:base].contiguous(),
-                 tile_ptr.to(torch.int32), cnt, max(1, min(groups, P, 8)), rpt_max)
+                 tile_ptr.to(torch.int32), cnt, normalize_groups(groups, P), rpt_max)
 
 
 def tile_row_counts(t: Tiles, tile: int) -> torch.Tensor:
