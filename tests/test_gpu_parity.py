@@ -585,3 +585,74 @@ def test_tiled_float64_matches_csr_float64(monkeypatch):
     np.testing.assert_allclose(eb, ea, rtol=1e-10)
     for key in ("pr", "dr", "gap", "p", "d_adj", "kkt"):
         np.testing.assert_allclose(kb[key], ka[key], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("case", ["no_ineq", "all_ineq", "empty_row_and_col", "one_by_one", "free_and_fixed"])
+def test_edge_cases_match_oracle(case):
+    """shapes the reference's own callers can produce: no '>=' block, no '=' block, empty rows/columns, 1 x 1,
+    free and fixed variables (all four bound classes of project_lambda_box)"""
+    rng = np.random.default_rng(21)
+    if case == "one_by_one":
+        m, n, m_ineq = 1, 1, 1
+        Kd = np.array([[2.0]], np.float32)
+    else:
+        m, n = 37, 23
+        Kd = (rng.standard_normal((m, n)) * (rng.random((m, n)) < 0.2)).astype(np.float32)
+        m_ineq = {"no_ineq": 0, "all_ineq": m}.get(case, 15)
+        if case == "empty_row_and_col":
+            Kd[5, :] = 0
+            Kd[30, :] = 0
+            Kd[:, 7] = 0
+    c = rng.standard_normal(n).astype(np.float32)
+    q = rng.standard_normal(m).astype(np.float32)
+    l = np.full(n, -1.0, np.float32)
+    u = np.full(n, 2.0, np.float32)
+    if case == "free_and_fixed":
+        l[::4], u[::4] = -np.inf, np.inf          # free
+        l[1::4], u[1::4] = 0.5, 0.5               # fixed
+        l[2::4] = -np.inf                         # upper only
+        u[3::4] = np.inf                          # lower only
+    o = orc.OracleLP.from_dense(Kd, m_ineq, c, q, l, u)
+    K = tp.CsrPair.from_dense(dev(Kd))
+    eng = tp.PdlpEngine.from_full(K, dev(c), dev(q), dev(l), dev(u), m_ineq)
+    x0 = np.clip(rng.standard_normal(n), np.where(np.isinf(l), -3, l), np.where(np.isinf(u), 3, u)).astype(np.float32)
+    y0 = rng.standard_normal(m).astype(np.float32)
+    y0[:m_ineq] = np.abs(y0[:m_ineq])
+    for adaptive in (False, True):
+        eng.set_iterate(dev(x0), dev(y0))
+        eng.set_step(0.1, 0.8, 1.0, 0)
+        eng.iterate(6, adaptive)
+        xo, yo, e = x0, y0, np.float32(0.1)
+        for k in range(1, 7):
+            if adaptive:
+                xo, yo, _, e, _ = o.step_adaptive(xo, yo, e, 0.8, 1.0, k)
+            else:
+                xo, yo = o.step_fixed(xo, yo, e, 0.8, 1.0)
+        x, y = eng.get_iterate(N.CUR)
+        close(x, xo, 3e-5)
+        close(y, yo, 3e-5)
+        got, ref = eng.kkt(N.CUR, 0.8), o.kkt(xo, yo, 0.8)
+        for key in ("pr", "dr", "gap", "p", "d_adj", "kkt"):
+            np.testing.assert_allclose(got[key], float(ref[key]), rtol=1e-4, atol=2e-5, err_msg=f"{case}:{key}")
+    # the un-scaled KKT variant with identity scalings equals the scaled one
+    e2 = tp.PdlpEngine.from_full(K, dev(c), dev(q), dev(l), dev(u), m_ineq, d_col=torch.ones(n, device=DEV), d_row=torch.ones(m, device=DEV))
+    e2.set_iterate(dev(x0), dev(y0))
+    a, b = e2.kkt(N.CUR, 0.8), e2.kkt(N.CUR, 0.8, unscaled=True)
+    assert a == b
+
+
+def test_unscaled_kkt_equals_kkt_of_the_unscaled_problem(golden):
+    """pdhg.py:157-161: residuals of the ORIGINAL problem from the Ruiz-scaled matrix and D_col, D_row"""
+    g = golden("ruiz.npz")
+    r = g.group("mixed_400x300/plain/it20")
+    Ks, c_s, q_s, l_s, u_s, (D_col, D_row, *_), _ = tp.ruiz_precondition(dev(r["c"]), dev(r["K"]), dev(r["q"]), dev(r["l"]), dev(r["u"]), device=DEV)
+    m, n = r["K"].shape
+    eng = tp.PdlpEngine.from_full(Ks, c_s, q_s, l_s, u_s, 320, d_col=D_col, d_row=D_row)
+    rng = np.random.default_rng(2)
+    xs, ys = rng.standard_normal(n).astype(np.float32), rng.standard_normal(m).astype(np.float32)
+    eng.set_iterate(dev(xs), dev(ys))
+    got = eng.kkt(N.CUR, 1.0, unscaled=True)
+    o = orc.OracleLP.from_dense(r["K"], 320, r["c"], r["q"], r["l"], r["u"])
+    ref = o.kkt(D_col.cpu().numpy().ravel() * xs, D_row.cpu().numpy().ravel() * ys, 1.0)
+    for key in ("pr", "dr", "gap", "p", "d_adj"):
+        np.testing.assert_allclose(got[key], float(ref[key]), rtol=2e-4, atol=2e-4, err_msg=key)

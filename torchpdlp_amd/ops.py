@@ -52,7 +52,7 @@ def _engine(K, c, q, l, u, m_ineq) -> PdlpEngine:
     Kp = _pair(K, dev)
     vec = lambda v, ln: as_vec(v, ln, dev, Kp.dtype)
     c, q, l, u = vec(c, Kp.n), vec(q, Kp.m), vec(l, Kp.n), vec(u, Kp.n)
-    key = (id(Kp), int(m_ineq), c.data_ptr(), q.data_ptr(), l.data_ptr(), u.data_ptr(), c._version, q._version, l._version, u._version)
+    key = (id(Kp), Kp.val.data_ptr(), Kp.nnz, int(m_ineq), c.data_ptr(), q.data_ptr(), l.data_ptr(), u.data_ptr(), c._version, q._version, l._version, u._version)
     eng = _engines.get(key)
     if eng is None:
         eng = PdlpEngine.from_full(Kp, c, q, l, u, int(m_ineq))
