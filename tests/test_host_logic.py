@@ -1,0 +1,171 @@
+"""The host side of the solver (torchpdlp_amd/solver.py: restart decisions, counters, primal weight, termination)
+without a GPU: a stand-in engine with the PdlpEngine interface whose arithmetic is the CPU ORACLE, driven by the
+product's own ``run_pdlp`` / ``PdhgDriver``, against the reference's recorded runs (tests/golden/solve_trace.npz).
+This checks the control flow the HIP engine plugs into; the kernels themselves are checked on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from torchpdlp_amd import _native as N
+from torchpdlp_amd.solver import PdhgDriver, run_pdlp
+
+
+class OracleEngine:
+    """PdlpEngine's interface (what solver.py uses) on top of oracle.OracleLP -- tests only."""
+
+    def __init__(self, o: orc.OracleLP, unscaled=None):
+        self.o, self.unscaled = o, unscaled          # unscaled = (D_col, D_row, OracleLP of the original problem)
+        self.dtype, self.device, self.comm = torch.float32, torch.device("cpu"), None
+        self.n, self.m, self.nl, self.ml = o.n, o.m, o.n, o.m
+        self.q, self.c = torch.from_numpy(o.q), torch.from_numpy(o.c)
+        self.t = np.float32
+
+    def set_iterate(self, x, y):
+        self.x, self.y = x.numpy().astype(np.float32).copy(), y.numpy().astype(np.float32).copy()
+        self.xp, self.yp = self.x, self.y
+        self._reset()
+        self.x_last, self.y_last = self.x.copy(), self.y.copy()
+
+    def _reset(self):
+        self.xs, self.ys, self.es = np.zeros_like(self.x), np.zeros_like(self.y), self.t(0)
+
+    def set_step(self, eta, omega, theta=1.0, iteration=0):
+        self.eta, self.omega, self.theta, self.k = self.t(eta), self.t(omega), theta, int(iteration)
+
+    def set_omega(self, omega):
+        self.omega = self.t(omega)
+
+    def iterate(self, iters, adaptive):
+        for _ in range(iters):
+            self.k += 1
+            self.xp, self.yp = self.x, self.y
+            if adaptive:
+                self.x, self.y, w, self.eta, _ = self.o.step_adaptive(self.x, self.y, self.eta, self.omega, self.theta, self.k)
+            else:
+                self.x, self.y = self.o.step_fixed(self.x, self.y, self.eta, self.omega, self.theta)
+                w = self.eta
+            self.xs += w * self.x
+            self.ys += w * self.y
+            self.es = self.t(self.es + w)
+
+    def flush_average(self):
+        pass
+
+    def compute_average(self):
+        self.xa, self.ya = self.xs / self.es, self.ys / self.es
+
+    def kkt(self, which, omega, unscaled=False):
+        x, y = {N.CUR: (self.x, self.y), N.AVG: (getattr(self, "xa", None), getattr(self, "ya", None)), N.PREV: (self.xp, self.yp)}[which]
+        if unscaled:
+            D_col, D_row, ou = self.unscaled
+            r = ou.kkt(D_col * x, D_row * y, omega)
+        else:
+            r = self.o.kkt(x, y, omega)
+        return {k: float(v) for k, v in r.items()}
+
+    def restart(self, which):
+        if which == N.AVG:
+            self.x, self.y = self.xa, self.ya
+        self._reset()
+
+    def restart_distance(self):
+        return (float(np.sum((self.x_last - self.x).astype(np.float64) ** 2)), float(np.sum((self.y_last - self.y).astype(np.float64) ** 2)))
+
+    def mark_restart_point(self):
+        self.x_last, self.y_last = self.x.copy(), self.y.copy()
+
+    def power_iteration(self, b0, iters):
+        return float(self.o.power_iter(b0.numpy(), iters))
+
+    def get_iterate(self, which=N.CUR):
+        return torch.from_numpy(self.x.copy()), torch.from_numpy(self.y.copy())
+
+    def synchronize(self):
+        pass
+
+
+def _lp(g, name):
+    a = g.group(name)
+    return orc.OracleLP(a["m"], a["n"], a["m_ineq"], a["rowptr"], a["colidx"], a["val"], a["c"], a["q"], a["l"], a["u"])
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _one_thread():
+    orc.set_threads(1)
+
+
+RUNS = [(n, f"{a}_{p}") for n in ("mixed_27x32", "mixed_400x300", "box_200x150") for a in ("fixed", "adaptive") for p in ("nopw", "pw")]
+
+
+@pytest.mark.parametrize("name,mode", RUNS)
+def test_driver_follows_the_reference_run(golden, name, mode):
+    g = golden("solve_trace.npz")
+    o = _lp(g, name)
+    r = g.group(f"{name}/{mode}")
+    adaptive, pw = mode.startswith("adaptive"), mode.endswith("_pw")
+    trace = dict(kkt=[], omega=[], restarts=[])
+    x, obj, k, n, j, status, _ = run_pdlp(OracleEngine(o), tol=1e-4, verbose=False, primal_update=pw, adaptive=adaptive,
+                                          sigma=float(r["sigma"]), trace=trace)
+    assert status == "Solved" == str(r["status"])
+    checks = len(trace["kkt"]) - n
+    assert checks % 3 == 0 and j == k + checks + 2 * n                       # pdhg.py:86/93,128,154,165
+    # the product's loop and the oracle's restatement of the reference loop take the same path, step for step
+    xo, objo, ko, no, jo, so, _, to = orc.pdlp_algorithm(o, tol=1e-4, adaptive=adaptive, primal_update=pw, sigma=np.float32(r["sigma"]))
+    assert (k, n, j, status) == (ko, no, jo, so)
+    assert trace["restarts"] == to["restarts"]
+    np.testing.assert_allclose(trace["kkt"], to["kkt"], rtol=1e-6)
+    np.testing.assert_allclose(trace["omega"], to["omega"], rtol=1e-6)
+    np.testing.assert_allclose(x.numpy(), xo, rtol=1e-6, atol=1e-7)
+    # and the reference's own record: identical decisions while rounding has not split the runs
+    nfirst = 1 if adaptive else min(len(trace["restarts"]), len(r["restarts"]), 6)
+    assert [tuple(v) for v in trace["restarts"][:nfirst]] == [tuple(int(t) for t in v) for v in r["restarts"][:nfirst]]
+    if not adaptive and not pw:
+        assert (k, n, j) == (int(r["k"]), int(r["n"]), int(r["j"]))
+    assert abs(obj - float(r["obj"])) <= 2e-3 * (1 + abs(float(r["obj"])))
+
+
+def test_kkt_pass_cap_and_time_limit(golden):
+    g = golden("solve_trace.npz")
+    o = _lp(g, "mixed_400x300")
+    sig = float(g.group("mixed_400x300/fixed_nopw")["sigma"])
+    x, obj, k, n, j, status, _ = run_pdlp(OracleEngine(o), max_kkt=100, verbose=False, sigma=sig)
+    # pdhg.py:54,67: both loops stop once j >= max_kkt; the post-loop work (n += 1, two more passes) still runs
+    xo, _, ko, no, jo, so, _, _ = orc.pdlp_algorithm(o, max_kkt=100, sigma=np.float32(sig))
+    assert (k, n, j, status) == (ko, no, jo, so)
+    assert status == "Unsolved (KKT passes limit exceeded)" and 100 <= j <= 106 and k < 100 and n >= 1
+    x, obj, k, n, j, status, _ = run_pdlp(OracleEngine(o), time_limit=0, verbose=False, sigma=sig)
+    assert status == "Unsolved (Time limit exceeded)" and (k, n, j) == (0, 0, 0) and np.isnan(obj)
+
+
+def test_lazy_previous_kkt_changes_nothing(golden):
+    """without a trace the driver evaluates KKT(previous) only when the 'necessary' test can fire"""
+    g = golden("solve_trace.npz")
+    o = _lp(g, "box_200x150")
+    sig = float(g.group("box_200x150/fixed_pw")["sigma"])
+    a = run_pdlp(OracleEngine(o), verbose=False, primal_update=True, sigma=sig, trace=dict(kkt=[], omega=[], restarts=[]))
+    calls = []
+    eng = OracleEngine(o)
+    orig = eng.kkt
+    eng.kkt = lambda which, omega, unscaled=False: (calls.append(which), orig(which, omega, unscaled))[1]
+    b = run_pdlp(eng, verbose=False, primal_update=True, sigma=sig)
+    assert a[1:6] == b[1:6] and np.array_equal(a[0].numpy(), b[0].numpy())
+    assert calls.count(N.PREV) < calls.count(N.CUR)
+
+
+def test_preconditioned_run_terminates_on_unscaled_residuals(golden):
+    g = golden("solve_trace.npz")
+    ou = _lp(g, "mixed_400x300")
+    os_, D_col, D_row, _ = ou.ruiz()
+    sig = float(os_.power_iter(np.ones(os_.n, np.float32), 50))
+    drv_calls = []
+    eng = OracleEngine(os_, unscaled=(D_col, D_row, ou))
+    orig = eng.kkt
+    eng.kkt = lambda which, omega, unscaled=False: (drv_calls.append(unscaled), orig(which, omega, unscaled))[1]
+    x, obj, k, n, j, status, _ = run_pdlp(eng, verbose=False, precondition=True, primal_update=True, adaptive=True, sigma=sig)
+    assert status == "Solved" and drv_calls.count(True) == n                    # one un-scaled evaluation per restart (pdhg.py:157-161)
+    xo, objo, ko, no, jo, so, _, _ = orc.pdlp_algorithm(os_, precondition=True, primal_update=True, adaptive=True,
+                                                          data_precond=(D_col, D_row, ou), sigma=np.float32(sig))
+    assert (k, n, j, status) == (ko, no, jo, so) and abs(obj - objo) <= 1e-5 * (1 + abs(objo))
+    opt = float(g.group("mixed_400x300/fixed_nopw")["opt_obj"])
+    assert abs(obj - opt) <= 2e-3 * (1 + abs(opt))

@@ -45,7 +45,11 @@ def primal_weight_from_distances(dx2: float, dy2: float, omega, smooth_theta=0.5
     """primal_weight_update (enhancements.py:73-78) given the two squared restart distances."""
     dxn, dyn = t(np.sqrt(dx2)), t(np.sqrt(dy2))
     if dxn > 0 and dyn > 0:
-        return t(np.exp(t(smooth_theta) * t(np.log(dyn / dxn)) + (t(1) - t(smooth_theta)) * t(np.log(t(omega)))))
+        # every intermediate is rounded to the working precision, as the reference's 0-dim tensors are;
+        # log / exp are evaluated in double and rounded once (same definition as oracle/pdlp_oracle_impl.inc)
+        lr = t(np.log(np.float64(t(dyn / dxn))))
+        lw = t(np.log(np.float64(t(omega))))
+        return t(np.exp(np.float64(t(t(smooth_theta) * lr) + t((t(1) - t(smooth_theta)) * lw))))
     return t(omega)
 
 
