@@ -70,3 +70,36 @@ def test_cli_writes_the_reference_csv_schema(tmp_path):
     assert by["afiro.mps"]["Status"] == "Solved" and abs(float(by["afiro.mps"]["Objective"]) - AFIRO_OPT) < 0.5
     assert by["marker.mps"]["Status"].startswith("Solver failed: could not convert string to float")   # and the run went on
     assert by["all_eq.mps"]["Status"] == "Solved" and by["all_ineq.mps"]["Status"] == "Solved"
+
+
+def test_fishnet_warm_start_matches_the_oracle_restatement(golden):
+    """spectral_casting.py:65-159 (opt-in --fishnet): same population, same breeding weights -> same survivor"""
+    from oracle import oracle as orc
+    from torchpdlp_amd import _native as N
+    g = golden("solve_trace.npz")
+    a = g.group("mixed_400x300")
+    o = orc.OracleLP(a["m"], a["n"], a["m_ineq"], a["rowptr"], a["colidx"], a["val"], a["c"], a["q"], a["l"], a["u"])
+    orc.set_threads(1)
+    t = lambda v, dt=torch.float32: torch.tensor(np.asarray(v), dtype=dt, device="cuda:0")
+    K = tp.CsrPair(int(a["m"]), int(a["n"]), t(a["rowptr"], torch.int32), t(a["colidx"], torch.int32), t(a["val"]))
+    eng = tp.PdlpEngine.from_full(K, t(a["c"]), t(a["q"]), t(a["l"]), t(a["u"]), int(a["m_ineq"]))
+    gen = torch.Generator().manual_seed(5)
+    pts, r = tp.sample_points(eng, 3, gen)                     # 8 points
+    assert pts.shape == (300, 8) and abs(r - float(g.group("mixed_400x300/fixed_nopw")["sigma"])) < 0.05 * r
+    np.testing.assert_allclose(torch.norm(pts - r / 300 ** 0.5, dim=0).numpy(), r, rtol=1e-4)   # all on the sphere
+    eta = 0.9 / r
+    gen2 = torch.Generator().manual_seed(6)
+    x, y = tp.fishnet(eng, pts.clone(), s=2, k=8, eta=eta, generator=gen2)
+    gen3 = torch.Generator().manual_seed(6)
+
+    def weights():
+        n_keep = [2]          # 8 -> 4 (round 0, no breeding) -> 2 (round 1: breed 4-2-1 = 1 point from 2 survivors) ...
+        while True:
+            yield torch.rand(n_keep[0], generator=gen3).numpy()
+    xo, yo = orc.fishnet(o, pts.numpy(), s=2, k=8, eta=eta, weights=weights())
+    np.testing.assert_allclose(x.cpu().numpy(), xo, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(y.cpu().numpy(), yo, rtol=2e-4, atol=2e-4)
+    # as a warm start it is accepted by the solver (x_init / y_init of pdlp_algorithm, pdhg.py:31-33)
+    xs, obj, k, n, j, status, _ = tp.pdlp_algorithm(K, int(a["m_ineq"]), t(a["c"]), t(a["q"]), t(a["l"]), t(a["u"]), "cuda:0",
+                                                    verbose=False, adaptive=True, primal_update=True, x_init=x, y_init=y, seed=1)
+    assert status == "Solved" and abs(obj - float(g.group("mixed_400x300/fixed_nopw")["opt_obj"])) < 0.2

@@ -16,5 +16,6 @@ from .precondition import ruiz_precondition                              # noqa:
 from .synthetic import SyntheticLP, gen_lp                               # noqa: F401
 from .mps import mps_to_standard_form, parse_mps                         # noqa: F401
 from .api import LPResult, solve_lp                                      # noqa: F401
+from .spectral_casting import fishnet, sample_points, spectral_cast      # noqa: F401
 
 __version__ = "0.1.0"

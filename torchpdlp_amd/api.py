@@ -33,7 +33,8 @@ class LPResult:
 def solve_lp(problem: Union[str, os.PathLike, tuple], device=None, tol: float = 1e-4, precondition: bool = False,
              primal_weight_update: bool = False, adaptive_stepsize: bool = False, max_kkt: int = 100_000,
              time_limit: float = 3600, verbose: bool = False, restart_period: int = 40, dtype=torch.float32,
-             seed: Optional[int] = None, compat: bool = True, x_init=None, y_init=None, trace=None) -> LPResult:
+             seed: Optional[int] = None, compat: bool = True, x_init=None, y_init=None, trace=None,
+             fishnet: bool = False) -> LPResult:
     """Solve ``min c'x, K[:m_ineq]x >= q[:m_ineq], K[m_ineq:]x = q[m_ineq:], l <= x <= u`` on the current HIP device.
 
     ``problem`` is an MPS path or ``(c, K, q, m_ineq, l, u)`` with ``K`` dense / COO / scipy-sparse / ``CsrPair``.
@@ -50,6 +51,13 @@ def solve_lp(problem: Union[str, os.PathLike, tuple], device=None, tol: float = 
     Ks, cs, qs, ls, us = K, c, q, l, u
     if precondition:                                                    # main.py:106-110
         Ks, cs, qs, ls, us, data_precond, time_used = ruiz_precondition(c, K, q, l, u, device=device)
+    if fishnet:                                                         # main.py:114-125 (k=32 points rounds, 2^5 points)
+        import time as _time
+        from .spectral_casting import spectral_cast
+        t0 = _time.time()
+        gen = None if seed is None else torch.Generator().manual_seed(int(seed))
+        x_init, y_init = spectral_cast(Ks, cs, qs, ls, us, m_ineq, k=32, device=device, generator=gen)
+        time_used += _time.time() - t0
     x, obj, k, n, j, status, total = pdlp_algorithm(
         Ks, m_ineq, cs, qs, ls, us, device, max_kkt=max_kkt, tol=tol, verbose=verbose, restart_period=restart_period,
         precondition=precondition, primal_update=primal_weight_update, adaptive=adaptive_stepsize,

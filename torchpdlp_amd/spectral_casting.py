@@ -1,0 +1,92 @@
+""""Fishnet" warm start -- counterpart of ``/root/reference/PDLP/spectral_casting.py`` (opt-in ``--fishnet``,
+``main.py:114-125``): cast 2^i points on a sphere of radius ||K||_2, run k fixed-step PDHG iterations on every point,
+keep the best 1/s by (signed) duality gap, on odd rounds breed the population back with random convex combinations
+plus the midpoint, until one point is left.
+
+The reference advances all points at once as an n x j matrix (``PDHG_step`` :254-293); the points are independent,
+so here each point runs through the same fused single-vector kernels the solver uses (``PdlpEngine.iterate`` /
+``kkt``).  Batching the points into one multi-vector pass over the matrix is future work.
+Randomness: the reference draws from the global torch RNG on the device; pass ``generator`` (a CPU generator) to
+pin the points and the breeding weights.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _native as N
+from .engine import PdlpEngine
+from .sparse import CsrPair, as_vec
+
+
+def sample_points(eng: PdlpEngine, i: int, generator: Optional[torch.Generator] = None, r: Optional[float] = None,
+                  b0: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, float]:
+    """2^i points on the sphere of radius r = ||K||_2 (25 power iterations) centred at (r/sqrt(n)) 1 -- :32-63"""
+    n = eng.n
+    if r is None:
+        if b0 is None:
+            b0 = torch.randn(n, generator=generator, dtype=torch.float32)
+        r = eng.power_iteration(b0, 25)
+    pts = torch.randn(n, 2 ** i, generator=generator, dtype=torch.float32)
+    pts = pts * r / torch.norm(pts, dim=0, keepdim=True)
+    pts += (r / n ** 0.5) * torch.ones(n, 1)
+    return pts, r
+
+
+def _gap(res: dict) -> float:
+    return res["gap"]            # adjusted_dual - prim_obj, signed (:233)
+
+
+def fishnet(eng: PdlpEngine, pts: torch.Tensor, s: int = 2, k: int = 32, eta: Optional[float] = None,
+            generator: Optional[torch.Generator] = None, b0: Optional[torch.Tensor] = None):
+    """``fishnet`` (:65-159) on an engine; ``pts`` is n x j on the host.  Returns (x, y) flattened on the device."""
+    dev, dt = eng.device, eng.dtype
+    pts = pts.to(torch.float32)
+    j = pts.shape[1]
+    # pts_y = K @ pts (:100)
+    ys = torch.stack([eng.spmv(pts[:, p].to(dev), False).cpu() for p in range(j)], dim=1)
+    if eta is None:                                                   # init_PDHG_vars :161-189
+        if b0 is None:
+            b0 = torch.randn(eng.n, generator=generator, dtype=torch.float32)
+        eta = 0.9 / eng.power_iteration(b0, 50)
+    q_norm, c_norm = float(torch.linalg.norm(eng.q)), float(torch.linalg.norm(eng.c))
+    omega = c_norm / q_norm if (q_norm > 1e-6 and c_norm > 1e-6) else 1.0
+    eng.set_step(eta, omega, 1.0, 0)
+    i = 0
+    while j > 1:                                                      # :105
+        gaps = []
+        for p in range(j):                                            # k PDHG steps on every point (:107-109)
+            eng.set_iterate(pts[:, p].to(dev), ys[:, p].to(dev))
+            eng.iterate(k, False)
+            x, y = eng.get_iterate(N.CUR)
+            pts[:, p], ys[:, p] = x.cpu(), y.cpu()
+            gaps.append(_gap(eng.kkt(N.CUR, omega)))                  # get_best_pts :191-252 (duality gap only)
+        old_j = j
+        order = torch.argsort(torch.tensor(gaps, dtype=torch.float32))                   # ascending (:238)
+        keep = max(1, old_j // s)
+        pts, ys = pts[:, order][:, :keep].clone(), ys[:, order][:, :keep].clone()
+        new_j = keep
+        if i % 2 == 1 and new_j > 1:                                  # breed on odd rounds (:117-152)
+            mid, mid_y = pts.mean(dim=1, keepdim=True), ys.mean(dim=1, keepdim=True)
+            new_x, new_y = [], []
+            for _ in range(old_j - new_j - 1):
+                w = torch.rand(new_j, generator=generator)
+                w = w / w.sum()
+                new_x.append(pts @ w.view(-1, 1))
+                new_y.append(ys @ w.view(-1, 1))
+            if new_x:
+                pts = torch.cat([pts] + new_x + [mid], dim=1)
+                ys = torch.cat([ys] + new_y + [mid_y], dim=1)
+        j = pts.shape[1]
+        i += 1
+    return pts.flatten().to(dev, dt), ys.flatten().to(dev, dt)
+
+
+def spectral_cast(K, c, q, l, u, m_ineq, k, s=2, i=5, device=None, generator: Optional[torch.Generator] = None):
+    """Drop-in for ``spectral_cast(K,c,q,l,u,m_ineq,k,s=2,i=5,device)`` (:5-29) -> ``(x0, y0)`` for ``pdlp_algorithm``."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    Kp = CsrPair.from_any(K, device=device)
+    eng = PdlpEngine.from_full(Kp, as_vec(c), as_vec(q), as_vec(l), as_vec(u), int(m_ineq))
+    pts, _ = sample_points(eng, i, generator)
+    return fishnet(eng, pts, s, k, generator=generator)
