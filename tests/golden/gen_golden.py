@@ -358,3 +358,4 @@ if __name__ == "__main__":
     if "g8" in which: g8_mps()
     if "g9" in which: g9_afiro()
     print("golden fixtures written to", HERE)
+
