@@ -10,7 +10,8 @@ from torchpdlp_amd.tiled import build_tiles
 
 n = int(os.environ.get("N", 10_000_000)); k = int(os.environ.get("K", 100)); lw = int(os.environ.get("LW", 16))
 m = int(os.environ.get("M", n))      # rows (n = columns): M=1250000 is one rank's shard of the bench problem on 8 GPUs
-groups = os.environ.get("GROUPS")
+groups = os.environ.get("NGROUPS")
+rpt = os.environ.get("RPT")
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev); g.manual_seed(0)
 col = torch.empty(m * k, dtype=torch.int32, device=dev)
@@ -26,7 +27,7 @@ zm = torch.zeros(m, device=dev)
 one = torch.zeros(2, dtype=torch.int32, device=dev)
 eng = tp.PdlpEngine(m, n, 0, (rp, col, val), (torch.zeros(n + 1, dtype=torch.int32, device=dev), one[:0], z[:0]), z, zm, z, z)
 t_csr = eng._time_spmv(0, z, torch.empty(m, device=dev))
-t = build_tiles(rp, col, val, m, n, lw=lw, groups=None if groups is None else int(groups))
+t = build_tiles(rp, col, val, m, n, lw=lw, rpt=None if rpt is None else int(rpt), groups=None if groups is None else int(groups))
 eng.attach_tiles(0, t)
 x = torch.randn(n, device=dev, generator=g)
 out = eng.spmv(x)

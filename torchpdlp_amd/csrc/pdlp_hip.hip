@@ -312,6 +312,13 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
     int i1 = has_panels ? tile_ptr[tile0 + p_lo + 1] : 0;
     load_group(i0, i1);
 
+#ifdef PDLP_STAMPS     /* diagnostic build (tools/ablate_tiled.sh): where a tile's cycles go; never shipped */
+    unsigned long long st_p1 = 0, st_s1 = 0, st_p2 = 0, st_s2 = 0, st_t;
+#define STAMP(acc) do { const unsigned long long n_ = __builtin_readcyclecounter(); acc += n_ - st_t; st_t = n_; } while (0)
+    st_t = __builtin_readcyclecounter();
+#else
+#define STAMP(acc) do { } while (0)
+#endif
     for (int p = p_lo; p < p_hi; ++p) {
         const size_t tile = tile0 + p;
         const T* __restrict__ xin = vin + ((size_t)p << lw);
@@ -359,30 +366,63 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
             else load_group(i0n, i1n);
         }
         if (i0 >= i1) load_group(i0n, i1n);              // (an empty tile consumed nothing)
+        STAMP(st_p1);
         __syncthreads();
+        STAMP(st_s1);
         int start = incl - total;
 #pragma unroll
         for (int w = 0; w < TNT / 64; ++w) start += (w < wv) ? wsum[w] : 0;
-        // pass 2: segment sums of this thread's rows, in item order (measured: advancing four rows together or
-        // predicating the first items costs more LDS instructions than the per-row chains it saves)
+        // pass 2: segment sums of this thread's rows.  A thread's items are consecutive in LDS (its rows are
+        // consecutive and the slots are in row order), so the first four items of every row are read
+        // unconditionally -- plain LDS loads with no load-to-use chain and no exec masking; reading past a short
+        // row only touches the next row's items or the 8-word tail of the buffer -- and selected by the row's count.
+        // Counts above 4 (rare: 0.06 % of the (row, tile) pairs at 0.65 items per pair) finish in a loop.
+        // In-kernel stamps showed the per-row dependent loops of the first version taking 55 % of a workgroup's time.
 #ifndef PDLP_ABL_NOPASS2
 #pragma unroll
-        for (int r = 0; r < TRPT_MAX; ++r) {
-            if (r < rpt) {
-                const int c = (int)((cw[r >> 3] >> ((r & 7) * 4)) & 0xfu);
-                T s = (T)0;
-                for (int k = 0; k < c; ++k) s += prod[start + k];
-                start += c;
-                acc[r] += s;
+        for (int r = 0; r < TRPT_MAX; r += 4) {
+            if (r < rpt) {          // rpt is even and counts of rows >= rpt are zero
+                const uint32_t nib = (cw[r >> 3] >> ((r & 7) * 4)) & 0xffffu;
+                const int c0 = (int)(nib & 0xfu), c1 = (int)((nib >> 4) & 0xfu), c2 = (int)((nib >> 8) & 0xfu), c3 = (int)(nib >> 12);
+                const int o0 = start, o1 = o0 + c0, o2 = o1 + c1, o3 = o2 + c2;
+                start = o3 + c3;
+                T v[16];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v[k] = prod[o0 + k];
+                    v[4 + k] = prod[o1 + k];
+                    v[8 + k] = prod[o2 + k];
+                    v[12 + k] = prod[o3 + k];
+                }
+                const int cc[4] = {c0, c1, c2, c3};
+                const int oo[4] = {o0, o1, o2, o3};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = cc[q];
+                    T sum = c > 0 ? v[4 * q] : (T)0;
+                    sum += c > 1 ? v[4 * q + 1] : (T)0;
+                    sum += c > 2 ? v[4 * q + 2] : (T)0;
+                    sum += c > 3 ? v[4 * q + 3] : (T)0;
+                    if (c > 4)
+                        for (int k = 4; k < c; ++k) sum += prod[oo[q] + k];
+                    if (r + q < TRPT_MAX) acc[r + q] += sum;
+                }
             }
         }
 #else
         acc[1] += (T)(start + (int)cw[0]);
 #endif
+        STAMP(st_p2);
         __syncthreads();
+        STAMP(st_s2);
         i0 = i0n;
         i1 = i1n;
     }
+#ifdef PDLP_STAMPS
+    if (lane == 0 && (b % 97) == 0 && (wv == 0 || wv == 5))
+        printf("block %d wave %d: pass1 %llu  sync1 %llu  pass2 %llu  sync2 %llu cycles over %d tiles\n", b, wv, st_p1, st_s1, st_p2, st_s2,
+               p_hi - p_lo);
+#endif
     // The row sums sit in registers with thread t holding rows t*rpt .. t*rpt+rpt-1.  They go once through this
     // workgroup's slice of a global scratch vector (written here, re-read below by the same workgroup: 8 bytes
     // per row, L2 resident) so that the epilogue runs with consecutive lanes on consecutive rows and all of
