@@ -214,15 +214,17 @@ class PdlpEngine:
             N.check(self.lib.pdlp_iterate(self.h, int(iters), int(adaptive)), "pdlp_iterate")
             return
         a = int(adaptive)
+        lib, h, comm = self.lib, self.h, self.comm
+        xbar, red = self.buffer(N.BUF_XBAR), self.buffer(N.BUF_RED)      # fixed addresses
         for _ in range(int(iters)):
-            N.check(self.lib.pdlp_primal_half(self.h, a), "pdlp_primal_half")
-            self._gather(N.BUF_XBAR)                       # K xbar needs every rank's block of xbar
-            N.check(self.lib.pdlp_dual_half(self.h, a), "pdlp_dual_half")
-            self._gather(N.BUF_Y_CUR)                      # the next K'y needs every rank's block of y
+            N.check(lib.pdlp_primal_half(h, a), "pdlp_primal_half")
+            comm.all_gather(xbar)                          # K xbar needs every rank's block of xbar
+            N.check(lib.pdlp_dual_half(h, a), "pdlp_dual_half")
+            comm.all_gather(self.buffer(N.BUF_Y_CUR))      # the next K'y needs every rank's block of y (buffers alternate)
             if adaptive:
-                N.check(self.lib.pdlp_adaptive_reduce(self.h), "pdlp_adaptive_reduce")
-                self.comm.all_reduce_sum(self.buffer(N.BUF_RED))
-                N.check(self.lib.pdlp_adaptive_update(self.h), "pdlp_adaptive_update")
+                N.check(lib.pdlp_adaptive_reduce(h), "pdlp_adaptive_reduce")
+                comm.all_reduce_sum(red)
+                N.check(lib.pdlp_adaptive_update(h), "pdlp_adaptive_update")
         if not adaptive and iters > 0:
             N.check(self.lib.pdlp_fixed_advance(self.h, int(iters)), "pdlp_fixed_advance")
 
