@@ -656,3 +656,22 @@ def test_unscaled_kkt_equals_kkt_of_the_unscaled_problem(golden):
     ref = o.kkt(D_col.cpu().numpy().ravel() * xs, D_row.cpu().numpy().ravel() * ys, 1.0)
     for key in ("pr", "dr", "gap", "p", "d_adj"):
         np.testing.assert_allclose(got[key], float(ref[key]), rtol=2e-4, atol=2e-4, err_msg=key)
+
+
+def test_runs_are_bitwise_reproducible(monkeypatch):
+    """no atomics anywhere (row sums, norm partials and their final reduction all have a fixed order): two runs from
+    the same state give bit-identical iterates and step sizes, with the CSR kernel and with the tiled kernel"""
+    lp = gen_lp(300_000, 250_000, 3, seed=9, device=DEV, recipe="mixed")
+    K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PDLP_TILED", mode)
+        outs = []
+        for _ in range(2):
+            e = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
+            e.set_iterate(torch.zeros(lp.n, device=DEV), torch.zeros(lp.m, device=DEV))
+            e.set_step(0.05, 1.1, 1.0, 0)
+            e.iterate(60, True)
+            x, y = e.get_iterate(N.CUR)
+            outs.append((x.clone(), y.clone(), e.scalars()["eta"], e.kkt(N.CUR, 1.1)["kkt"]))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        assert outs[0][2] == outs[1][2] and outs[0][3] == outs[1][3]
