@@ -126,6 +126,39 @@ def cpu_baseline(args, sv_dtype):
                        f"rate scaled by nnz ratio {scale:.4g} to the full workload")
 
 
+def measure_roofline(args, eng, dt, adaptive, world):
+    """roofline of the dominant kernel (per launch, this rank's shard): algorithmic bytes / mean HIP-event duration"""
+    sv, si = (4 if dt == torch.float32 else 8), 4
+    nl, ml = eng.nl, eng.ml
+    nnz_k = int(eng.K[2].numel())
+    nnz_kt = int(eng.KT[2].numel())
+    b_primal, _ = algorithmic_bytes(nl, eng.m, nnz_kt, sv, si, adaptive)
+    _, b_dual = algorithmic_bytes(eng.n, ml, nnz_k, sv, si, adaptive)
+    a = int(adaptive)
+    ms_primal = time_kernel(eng, lambda: N.check(eng.lib.pdlp_primal_half(eng.h, a)), args.kernel_reps)
+    # the dual kernel flips the iterate buffers each launch: harmless for timing
+    ms_dual = time_kernel(eng, lambda: N.check(eng.lib.pdlp_dual_half(eng.h, a)), args.kernel_reps)
+    kfam = lambda t: "k_tiled_fused" if eng.tiles[t] is not None else "k_csr_fused"
+    if ms_primal >= ms_dual:
+        kname, kms, kbytes = f"{kfam(1)}<PrimalEpi> (K'y + primal update)", ms_primal, b_primal
+    else:
+        kname, kms, kbytes = f"{kfam(0)}<DualEpi> (K xbar + dual update)", ms_dual, b_dual
+    achieved = kbytes / (kms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")       # rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, see profiles/README.md
+    if os.path.exists(tfile):
+        try:
+            tj = json.load(open(tfile))
+            key = f"n{args.n}_k{args.nnz_per_row}_{args.dtype}_{args.mode}_g{world}_{kfam(1).split('_')[1]}"
+            traffic = tj.get(key, {}).get("primal" if ms_primal >= ms_dual else "dual")
+        except Exception:
+            traffic = None
+    roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, launch_ms=round(kms, 4),
+                    algorithmic_bytes=int(kbytes), other_kernel_ms=round(min(ms_primal, ms_dual), 4))
+    return roofline
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -182,35 +215,10 @@ def main():
         comm.dist.all_reduce(tt, op=comm.dist.ReduceOp.MAX)
         elapsed = float(tt)
 
-    # ---- roofline of the dominant kernel (per launch, this rank's shard) ---------------------------
-    sv, si = (4 if dt == torch.float32 else 8), 4
-    nl, ml = eng.nl, eng.ml
-    nnz_k = int(eng.K[2].numel())
-    nnz_kt = int(eng.KT[2].numel())
-    b_primal, _ = algorithmic_bytes(nl, eng.m, nnz_kt, sv, si, adaptive)
-    _, b_dual = algorithmic_bytes(eng.n, ml, nnz_k, sv, si, adaptive)
-    a = int(adaptive)
-    ms_primal = time_kernel(eng, lambda: N.check(eng.lib.pdlp_primal_half(eng.h, a)), args.kernel_reps)
-    # the dual kernel flips the iterate buffers each launch: harmless for timing
-    ms_dual = time_kernel(eng, lambda: N.check(eng.lib.pdlp_dual_half(eng.h, a)), args.kernel_reps)
-    kfam = lambda t: "k_tiled_fused" if eng.tiles[t] is not None else "k_csr_fused"
-    if ms_primal >= ms_dual:
-        kname, kms, kbytes = f"{kfam(1)}<PrimalEpi> (K'y + primal update)", ms_primal, b_primal
-    else:
-        kname, kms, kbytes = f"{kfam(0)}<DualEpi> (K xbar + dual update)", ms_dual, b_dual
-    achieved = kbytes / (kms * 1e-3) / 1e9
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "traffic.json")       # rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, see profiles/README.md
-    if os.path.exists(tfile):
-        try:
-            tj = json.load(open(tfile))
-            key = f"n{args.n}_k{args.nnz_per_row}_{args.dtype}_{args.mode}_g{world}_{kfam(1).split('_')[1]}"
-            traffic = tj.get(key, {}).get("primal" if ms_primal >= ms_dual else "dual")
-        except Exception:
-            traffic = None
-    roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, launch_ms=round(kms, 4),
-                    algorithmic_bytes=int(kbytes), other_kernel_ms=round(min(ms_primal, ms_dual), 4))
+    try:
+        roofline = measure_roofline(args, eng, dt, adaptive, world)
+    except Exception as e:          # the headline number must still be reported
+        roofline = {"bound": "hbm", "error": f"{type(e).__name__}: {e}"[:200]}
 
     out = {
         "metric": "PDHG iterations/sec", "value": round(args.steps / elapsed, 3), "unit": "iterations/s",
@@ -229,7 +237,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         del drv, eng
         torch.cuda.empty_cache()
-        out["cpu_baseline"] = cpu_baseline(args, dt)
+        try:
+            out["cpu_baseline"] = cpu_baseline(args, dt)
+        except Exception as e:
+            out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if comm is not None:
