@@ -199,7 +199,11 @@ __global__ __launch_bounds__(BLOCK) void k_csr_fused(const int32_t* __restrict__
         const int nn = e - a, nrows = r1 - r0;
         if (nn <= NNZ_CAP) {
             // stage the products: coalesced value/index reads, gathered vector reads
+#ifdef PDLP_ABL_NOGATHER      /* timing-only build */
+            for (int i = tid; i < nn; i += BLOCK) prod[i] = va[a + i] * (T)(ci[a + i] & 1);
+#else
             for (int i = tid; i < nn; i += BLOCK) prod[i] = va[a + i] * vin[ci[a + i]];
+#endif
             __syncthreads();
             // 1..64 lanes per row (a power of two, so a row never straddles a wave)
             int tpr = 1 << (31 - __clz(BLOCK / nrows));
