@@ -60,9 +60,12 @@ def test_build_and_replay(case):
 
 
 def test_not_eligible_when_a_tile_or_a_row_is_too_full():
-    rp, ci, va = _csr(640, 64, np.full(640, 10), 3)
-    assert build_tiles(rp, ci, va, 640, 64, lw=6, rpt=2, cap=2000) is None        # 640 rows x 10 = 6400 items in one tile
+    rp, ci, va = _csr(640, 64, np.full(640, 3), 3)
+    assert build_tiles(rp, ci, va, 640, 64, lw=6, rpt=2, cap=1000) is None        # 640 rows x 3 = 1920 items in one tile
     assert build_tiles(rp, ci, va, 640, 64, lw=6, rpt=2, cap=8000) is not None
+    rp, ci, va = _csr(640, 64, np.full(640, 5), 3)                                # 64 consecutive rows x 5 = 320 items of one
+    assert build_tiles(rp, ci, va, 640, 64, lw=6, rpt=2, cap=8000) is None        # tile: more than the 8-bit scan fields hold
+    assert build_tiles(rp, ci, va, 640, 64, lw=5, rpt=2, cap=8000) is not None    # (two panels: 160 per 64 rows)
     rp, ci, va = _csr(4, 600, np.array([30, 1, 1, 1]), 4)
     assert build_tiles(rp, ci, va, 4, 600, lw=10, rpt=2, cap=2000) is None        # 16+ entries of one row in one panel
     t64 = build_tiles(rp, ci, va.double(), 4, 600, lw=6, rpt=2)                     # float64: 3 count words, 8192-item tiles

@@ -43,6 +43,19 @@ enum { S_ETA = 0, S_OMEGA, S_THETA, S_TAU, S_SIGMA, S_WPEND, S_ETASUM, S_K, S_IN
 template <typename T> __device__ __forceinline__ T shfl_xor_t(T v, int m) { return __shfl_xor(v, m, 64); }
 
 // sum of `v` over the 256-thread workgroup, valid in thread 0.  `buf` holds >= 4 entries.
+// inclusive scan over the 64 lanes of a wave with DPP adds only (no LDS crossbar): Hillis-Steele inside each row of
+// 16 lanes, then row_bcast:15 / row_bcast:31 carry the row totals.  All 64 lanes must be active.
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x)
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);   // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);   // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
 template <typename T> __device__ __forceinline__ T block_sum(T v, T* buf)
 {
 #pragma unroll
@@ -327,29 +340,34 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
         const size_t tile = tile0 + p;
         const T* __restrict__ xin = vin + ((size_t)p << lw);
         const int i0n = i1, i1n = p + 1 < p_hi ? tile_ptr[tile + 2] : i1;       // the next tile (empty after the last)
-        // segment lengths of this thread's rows (4 bits each) and their offset inside the wave
+        // segment lengths (4 bits each) of this thread's rows: row i of lane l of wave w is row w*64*rpt + i*64 + l
+        // of the row block, so the 64 lanes of a wave sit on 64 consecutive rows for every i
         uint32_t cw[TCW];
         const uint32_t* cp = tcnt + (tile * TNT + tid) * TCW;
-        int total = 0;
+        uint32_t total = 0;
 #pragma unroll
         for (int q = 0; q < TCW; ++q) {
             cw[q] = __builtin_nontemporal_load(cp + q);
             const uint32_t n2 = (cw[q] & 0x0f0f0f0fu) + ((cw[q] >> 4) & 0x0f0f0f0fu);
-            total += (int)((n2 * 0x01010101u) >> 24);
+            total += (n2 * 0x01010101u) >> 24;
         }
-        int incl = total;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int o = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += o;
-        }
-        if (lane == 63) wsum[wv] = incl;
+        total = wave_incl_scan_u32(total);
+        if (lane == 63) wsum[wv] = (int)total;           // items of this wave's rows in this tile
         // pass 1, one register group at a time; the next group (of this tile or of the next) is loaded as soon as
         // the current one is consumed
         for (int g0 = i0; g0 < i1; g0 += TGRP) {
             T xg[TU * 4];
+#ifdef PDLP_SKIP_EMPTY
+            // chunks of the group that lie past the tile's end for this whole wave are skipped (wave-uniform)
+            bool on[TU];
 #pragma unroll
-            for (int u = 0; u < TU; ++u) {
+            for (int u = 0; u < TU; ++u) on[u] = g0 + (u * TNT + __builtin_amdgcn_readfirstlane(wv) * 64) * 4 < i1;
+#define PDLP_ON(u) on[u]
+#else
+#define PDLP_ON(u) true
+#endif
+#pragma unroll
+            for (int u = 0; u < TU; ++u) if (PDLP_ON(u)) {
 #ifdef PDLP_ABL_NOGATHER
                 xg[4 * u + 0] = xg[4 * u + 1] = xg[4 * u + 2] = xg[4 * u + 3] = (T)(pk[u].x & 1u);
 #else
@@ -360,7 +378,7 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
 #endif
             }
 #pragma unroll
-            for (int u = 0; u < TU; ++u) {
+            for (int u = 0; u < TU; ++u) if (PDLP_ON(u)) {
                 prod[pk[u].x >> lw] = vv[u].x * xg[4 * u + 0];
                 prod[pk[u].y >> lw] = vv[u].y * xg[4 * u + 1];
                 prod[pk[u].z >> lw] = vv[u].z * xg[4 * u + 2];
@@ -373,59 +391,61 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
         STAMP(st_p1);
         __syncthreads();
         STAMP(st_s1);
-        int start = incl - total;
+        int sb = 0;
 #pragma unroll
-        for (int w = 0; w < TNT / 64; ++w) start += (w < wv) ? wsum[w] : 0;
-        // pass 2: segment sums of this thread's rows.  A thread's items are consecutive in LDS (its rows are
-        // consecutive and the slots are in row order), so the first four items of every row are read
-        // unconditionally -- plain LDS loads with no load-to-use chain and no exec masking; reading past a short
-        // row only touches the next row's items or the 8-word tail of the buffer -- and selected by the row's count.
-        // Counts above 4 (rare: 0.06 % of the (row, tile) pairs at 0.65 items per pair) finish in a loop.
-        // In-kernel stamps showed the per-row dependent loops of the first version taking 55 % of a workgroup's time.
+        for (int w = 0; w < TNT / 64; ++w) sb += (w < wv) ? wsum[w] : 0;
+        uint32_t sbase = (uint32_t)__builtin_amdgcn_readfirstlane(sb);      // first slot of this wave's rows
+        // pass 2: segment sums.  The slots are in row order, so for a given i the 64 rows of the wave own one
+        // contiguous run of slots: a row's first slot is the wave's running base plus the exclusive scan of the
+        // lanes' counts.  Four row indices are scanned at once (8-bit fields of one word; the format guarantees
+        // that 64 consecutive rows hold fewer than 256 items of a tile).  Consecutive lanes then read (nearly)
+        // consecutive LDS words -- the earlier thread-owns-consecutive-rows mapping put lanes ~26 words apart
+        // and paid 4-way bank conflicts on every read.  The first four items of every row are read
+        // unconditionally and selected by the row's count (no load-to-use chains, no exec masking; reading past
+        // a short row touches the next rows' items or the 8-word tail of the buffer); longer segments (0.06 % of
+        // the (row, tile) pairs at 0.65 items per pair) finish in a loop.
 #ifndef PDLP_ABL_NOPASS2
-        constexpr int RG = 4;                            // rows advanced together (register budget)
-        if constexpr (sizeof(T) == 8) {                  // float64: the plain per-row loop measured faster (93 vs 86 it/s)
 #pragma unroll
-            for (int r = 0; r < TRPT_MAX; ++r) {
-                if (r < rpt) {
-                    const int c = (int)((cw[r >> 3] >> ((r & 7) * 4)) & 0xfu);
-                    T sum = (T)0;
-                    for (int k = 0; k < c; ++k) sum += prod[start + k];
-                    start += c;
-                    acc[r] += sum;
-                }
-            }
-        } else
+        for (int q = 0; q < TCW; ++q) {
+            if (8 * q < rpt) {
+                const uint32_t cE = cw[q] & 0x0f0f0f0fu, cO = (cw[q] >> 4) & 0x0f0f0f0fu;     // rows 8q+{0,2,4,6} | 8q+{1,3,5,7}
+                const uint32_t sE = wave_incl_scan_u32(cE), sO = wave_incl_scan_u32(cO);
+                const uint32_t tE = (uint32_t)__builtin_amdgcn_readlane((int)sE, 63), tO = (uint32_t)__builtin_amdgcn_readlane((int)sO, 63);
+                const uint32_t eE = sE - cE, eO = sO - cO;                                    // exclusive, field by field
 #pragma unroll
-        for (int r = 0; r < TRPT_MAX; r += RG) {
-            if (r < rpt) {          // rpt is even and counts of rows >= rpt are zero
-                int cc[RG], oo[RG];
+                for (int hf = 0; hf < 2; ++hf) {
+                    if (8 * q + 4 * hf < rpt) {         // rpt is even and counts of rows >= rpt are zero
+                        int cc[4], oo[4];
 #pragma unroll
-                for (int q = 0; q < RG; ++q) {
-                    cc[q] = (int)((cw[(r + q) >> 3] >> (((r + q) & 7) * 4)) & 0xfu);
-                    oo[q] = start;
-                    start += cc[q];
-                }
-                T v[RG * 4];
+                        for (int z = 0; z < 4; ++z) {
+                            const int j = 2 * hf + (z >> 1);                                  // field
+                            const bool odd = z & 1;
+                            cc[z] = (int)(((odd ? cO : cE) >> (8 * j)) & 0xffu);
+                            oo[z] = (int)(sbase + (((odd ? eO : eE) >> (8 * j)) & 0xffu));
+                            sbase += ((odd ? tO : tE) >> (8 * j)) & 0xffu;
+                        }
+                        T v[16];
 #pragma unroll
-                for (int q = 0; q < RG; ++q)
+                        for (int z = 0; z < 4; ++z)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[4 * q + k] = prod[oo[q] + k];
+                            for (int k = 0; k < 4; ++k) v[4 * z + k] = prod[oo[z] + k];
 #pragma unroll
-                for (int q = 0; q < RG; ++q) {
-                    const int c = cc[q];
-                    T sum = c > 0 ? v[4 * q] : (T)0;
-                    sum += c > 1 ? v[4 * q + 1] : (T)0;
-                    sum += c > 2 ? v[4 * q + 2] : (T)0;
-                    sum += c > 3 ? v[4 * q + 3] : (T)0;
-                    if (c > 4)
-                        for (int k = 4; k < c; ++k) sum += prod[oo[q] + k];
-                    acc[r + q] += sum;
+                        for (int z = 0; z < 4; ++z) {
+                            const int c = cc[z];
+                            T sum = c > 0 ? v[4 * z] : (T)0;
+                            sum += c > 1 ? v[4 * z + 1] : (T)0;
+                            sum += c > 2 ? v[4 * z + 2] : (T)0;
+                            sum += c > 3 ? v[4 * z + 3] : (T)0;
+                            if (c > 4)
+                                for (int k = 4; k < c; ++k) sum += prod[oo[z] + k];
+                            acc[8 * q + 4 * hf + z] += sum;
+                        }
+                    }
                 }
             }
         }
 #else
-        acc[1] += (T)(start + (int)cw[0]);
+        acc[1] += (T)(sbase + cw[0]);
 #endif
         STAMP(st_p2);
         __syncthreads();
@@ -438,24 +458,21 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
         printf("block %d wave %d: pass1 %llu  sync1 %llu  pass2 %llu  sync2 %llu cycles over %d tiles\n", b, wv, st_p1, st_s1, st_p2, st_s2,
                p_hi - p_lo);
 #endif
-    // The row sums sit in registers with thread t holding rows t*rpt .. t*rpt+rpt-1.  They go once through this
-    // workgroup's slice of a global scratch vector (written here, re-read below by the same workgroup: 8 bytes
-    // per row, L2 resident) so that the epilogue runs with consecutive lanes on consecutive rows and all of
-    // its vector traffic is coalesced.  (The 512*40 sums do not fit the 64 KB product buffer.)
+    // The row sums sit in registers, lane l of wave w holding rows w*64*rpt + i*64 + l: for every i the lanes are
+    // on consecutive rows, so the epilogue (or the store of the partial sums) is coalesced straight from registers.
     const int rb = TNT * rpt;
-    T* __restrict__ rs = rowsum + (size_t)grp * rs_stride + (size_t)b * rb;
+    const int row0 = b * rb + wv * 64 * rpt + lane;
+    if (!FUSED) {
+        T* __restrict__ rs = rowsum + (size_t)grp * rs_stride;
+#pragma unroll
+        for (int r = 0; r < TRPT_MAX; ++r)
+            if (r < rpt && row0 + 64 * r < nrows) rs[row0 + 64 * r] = acc[r];
+        return;
+    }
+    double accd[NACC] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int r = 0; r < TRPT_MAX; ++r)
-        if (r < rpt) rs[tid * rpt + r] = acc[r];
-    if (!FUSED) return;
-    __threadfence_block();
-    __syncthreads();
-    double accd[NACC] = {0.0, 0.0, 0.0, 0.0};
-    for (int i = 0; i < rpt; ++i) {
-        const int lrow = tid + i * TNT;
-        const int row = b * rb + lrow;
-        if (row < nrows) epi(row, __builtin_nontemporal_load(rs + lrow), accd);
-    }
+        if (r < rpt && row0 + 64 * r < nrows) epi(row0 + 64 * r, acc[r], accd);
     if (Epi::NA > 0) {
 #pragma unroll
         for (int r = 0; r < Epi::NA; ++r) {

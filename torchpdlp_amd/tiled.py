@@ -11,7 +11,10 @@ L2 resident and (b) consecutive lanes share cache lines.  So:
   lines of an L2-resident panel; all workgroups walk the panels in the same order at the same pace;
 * each item carries ``slot``, its rank in ROW order inside the tile: the product is written to
   ``lds[slot]`` (a transposition through LDS, plain stores, no atomics), after which every thread reduces
-  the segments of its ``rpt`` rows; segment lengths come from 4 bits per (tile, row).
+  the segments of its ``rpt`` rows; segment lengths come from 4 bits per (tile, row).  Lane ``l`` of wave ``w``
+  owns rows ``w*64*rpt + i*64 + l`` (``i < rpt``) of the row block: for every ``i`` a wave sits on 64 consecutive
+  rows, whose segments are one contiguous run of LDS words (conflict-free reads), and a row's first slot is a
+  wave scan of the counts away (done four ``i`` at a time in 8-bit fields).
 
 Item = 4-byte value + 4-byte ``(slot << lw) | (col - panel*W)``.  Tiles are padded to multiples of 256 items
 (zero value, unused slot) and streamed with 16-byte loads.  Gather cost on gfx950 grows with the number of
@@ -22,8 +25,8 @@ instruction j covers 64 CONSECUTIVE sorted items (about 25 lines at 100 non-zero
 spaced four apart (64 lines).  Bytes per non-zero: 8 + 20*512*P/nnz_per_block (the count nibbles): about 8.9 for 100 non-zeros per row at
 10M columns.
 
-A matrix is eligible when every tile holds at most ``cap`` items (16384 in float32, 8192 in float64) and no
-(tile, row) more than 15; otherwise ``build_tiles`` returns None and the CSR kernel is used.
+A matrix is eligible when every tile holds at most ``cap`` items (16384 in float32, 8192 in float64), no
+(tile, row) more than 15 and no 64 consecutive rows more than 255 items of one tile; otherwise ``build_tiles`` returns None and the CSR kernel is used.
 """
 from __future__ import annotations
 
@@ -178,13 +181,18 @@ def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, n
             tsz = torch.bincount(tile, minlength=ntl)
             if int(tsz.max()) > cap:
                 return None
-            # items of every (tile, row): 4 bits each, 24 per thread (thread t owns rows t*rpt .. t*rpt+rpt-1)
+            # items of every (tile, row): 4 bits each.  Lane l of wave w owns rows w*64*rpt + i*64 + l (i < rpt) of
+            # the row block -- for every i the 64 lanes of a wave sit on 64 consecutive rows -- and the kernel
+            # scans the lanes' counts in 8-bit fields, so 64 consecutive rows may hold at most 255 items of a tile
             c_tr = torch.bincount(tile * RB + (rloc - rblk * RB), minlength=ntl * RB)
             if int(c_tr.max()) > 15:
                 return None
+            c_w = c_tr.view(ntl, NT // 64, rpt, 64)
+            if int(c_w.sum(-1).max()) > 255:
+                return None
             nib = torch.zeros(ntl, NT, rpt_max, dtype=torch.int64, device=dev)     # CW words of 8 nibbles per thread
-            nib[:, :, :rpt] = c_tr.view(ntl, NT, rpt)
-            del c_tr
+            nib[:, :, :rpt] = c_w.permute(0, 1, 3, 2).reshape(ntl, NT, rpt)
+            del c_tr, c_w
             words = (nib.view(ntl, NT, CW, 8) << shifts).sum(-1)
             cnt[t0 * NT * CW:(t0 + ntl) * NT * CW] = _wrap_i32(words.reshape(-1))
             del nib, words
@@ -229,7 +237,8 @@ def tile_row_counts(t: Tiles, tile: int) -> torch.Tensor:
     w = t.cnt[tile * NT * CW:(tile + 1) * NT * CW].long() & 0xFFFFFFFF
     shifts = (torch.arange(8, device=w.device) * 4).view(1, 1, 8)
     nib = (w.view(NT, CW, 1) >> shifts) & 15
-    return nib.reshape(NT, t.rpt_max)[:, :t.rpt].reshape(-1)
+    per_thread = nib.reshape(NT // 64, 64, t.rpt_max)[:, :, :t.rpt]           # [wave, lane, i]
+    return per_thread.permute(0, 2, 1).reshape(-1)                          # row = wave*64*rpt + i*64 + lane
 
 
 def emulate_spmv(t: Tiles, x: torch.Tensor) -> torch.Tensor:
