@@ -301,11 +301,9 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
 #pragma unroll
     for (int r = 0; r < TRPT_MAX; ++r) acc[r] = (T)0;
 
-    u32x4 pk[TU];
-    V4 vv[TU];
     const uint32_t trash = (uint32_t)TCAP << lw;       // slot TCAP (past every real slot), column 0
     // the item stream is read once: non-temporal loads keep it from evicting the gathered panel out of the L2
-    auto load_group = [&](int g0, int i1) {
+    auto load_into = [&](u32x4 (&pk)[TU], V4 (&vv)[TU], int g0, int i1) {
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
             const int i = g0 + (u * TNT + tid) * 4;
@@ -323,11 +321,39 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
             }
         }
     };
+    // one register group: gathers, then the products go to their row-order slots in LDS.  Chunks of the group that
+    // lie past the tile's end for this whole wave are skipped (wave-uniform).
+    auto consume = [&](u32x4 (&pk)[TU], V4 (&vv)[TU], int g0, int i1, const T* __restrict__ xin) {
+        T xg[TU * 4];
+        bool on[TU];
+#pragma unroll
+        for (int u = 0; u < TU; ++u) on[u] = g0 + (u * TNT + __builtin_amdgcn_readfirstlane(wv) * 64) * 4 < i1;
+#pragma unroll
+        for (int u = 0; u < TU; ++u) if (on[u]) {
+#ifdef PDLP_ABL_NOGATHER
+            xg[4 * u + 0] = xg[4 * u + 1] = xg[4 * u + 2] = xg[4 * u + 3] = (T)(pk[u].x & 1u);
+#else
+            xg[4 * u + 0] = xin[pk[u].x & mask];
+            xg[4 * u + 1] = xin[pk[u].y & mask];
+            xg[4 * u + 2] = xin[pk[u].z & mask];
+            xg[4 * u + 3] = xin[pk[u].w & mask];
+#endif
+        }
+#pragma unroll
+        for (int u = 0; u < TU; ++u) if (on[u]) {
+            prod[pk[u].x >> lw] = vv[u].x * xg[4 * u + 0];
+            prod[pk[u].y >> lw] = vv[u].y * xg[4 * u + 1];
+            prod[pk[u].z >> lw] = vv[u].z * xg[4 * u + 2];
+            prod[pk[u].w >> lw] = vv[u].w * xg[4 * u + 3];
+        }
+    };
     const size_t tile0 = (size_t)b * npanel;
     const bool has_panels = p_lo < npanel;             // (pdlp_attach_tiles rejects group counts that leave a group empty)
+    u32x4 pk[TU];
+    V4 vv[TU];
     int i0 = has_panels ? tile_ptr[tile0 + p_lo] : 0;
     int i1 = has_panels ? tile_ptr[tile0 + p_lo + 1] : 0;
-    load_group(i0, i1);
+    load_into(pk, vv, i0, i1);
 
 #ifdef PDLP_STAMPS     /* diagnostic build (tools/ablate_tiled.sh): where a tile's cycles go; never shipped */
     unsigned long long st_p1 = 0, st_s1 = 0, st_p2 = 0, st_s2 = 0, st_t;
@@ -356,38 +382,11 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
         // pass 1, one register group at a time; the next group (of this tile or of the next) is loaded as soon as
         // the current one is consumed
         for (int g0 = i0; g0 < i1; g0 += TGRP) {
-            T xg[TU * 4];
-#ifdef PDLP_SKIP_EMPTY
-            // chunks of the group that lie past the tile's end for this whole wave are skipped (wave-uniform)
-            bool on[TU];
-#pragma unroll
-            for (int u = 0; u < TU; ++u) on[u] = g0 + (u * TNT + __builtin_amdgcn_readfirstlane(wv) * 64) * 4 < i1;
-#define PDLP_ON(u) on[u]
-#else
-#define PDLP_ON(u) true
-#endif
-#pragma unroll
-            for (int u = 0; u < TU; ++u) if (PDLP_ON(u)) {
-#ifdef PDLP_ABL_NOGATHER
-                xg[4 * u + 0] = xg[4 * u + 1] = xg[4 * u + 2] = xg[4 * u + 3] = (T)(pk[u].x & 1u);
-#else
-                xg[4 * u + 0] = xin[pk[u].x & mask];
-                xg[4 * u + 1] = xin[pk[u].y & mask];
-                xg[4 * u + 2] = xin[pk[u].z & mask];
-                xg[4 * u + 3] = xin[pk[u].w & mask];
-#endif
-            }
-#pragma unroll
-            for (int u = 0; u < TU; ++u) if (PDLP_ON(u)) {
-                prod[pk[u].x >> lw] = vv[u].x * xg[4 * u + 0];
-                prod[pk[u].y >> lw] = vv[u].y * xg[4 * u + 1];
-                prod[pk[u].z >> lw] = vv[u].z * xg[4 * u + 2];
-                prod[pk[u].w >> lw] = vv[u].w * xg[4 * u + 3];
-            }
-            if (g0 + TGRP < i1) load_group(g0 + TGRP, i1);
-            else load_group(i0n, i1n);
+            consume(pk, vv, g0, i1, xin);
+            if (g0 + TGRP < i1) load_into(pk, vv, g0 + TGRP, i1);
+            else load_into(pk, vv, i0n, i1n);
         }
-        if (i0 >= i1) load_group(i0n, i1n);              // (an empty tile consumed nothing)
+        if (i0 >= i1) load_into(pk, vv, i0n, i1n);       // (an empty tile consumed nothing)
         STAMP(st_p1);
         __syncthreads();
         STAMP(st_s1);
@@ -412,25 +411,26 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
                 const uint32_t sE = wave_incl_scan_u32(cE), sO = wave_incl_scan_u32(cO);
                 const uint32_t tE = (uint32_t)__builtin_amdgcn_readlane((int)sE, 63), tO = (uint32_t)__builtin_amdgcn_readlane((int)sO, 63);
                 const uint32_t eE = sE - cE, eO = sO - cO;                                    // exclusive, field by field
+                constexpr int RG = sizeof(T) == 8 ? 2 : 4;      // rows advanced together (register budget)
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    if (8 * q + 4 * hf < rpt) {         // rpt is even and counts of rows >= rpt are zero
-                        int cc[4], oo[4];
+                for (int g = 0; g < 8 / RG; ++g) {
+                    if (8 * q + RG * g < rpt) {         // rpt is even and counts of rows >= rpt are zero
+                        int cc[RG], oo[RG];
 #pragma unroll
-                        for (int z = 0; z < 4; ++z) {
-                            const int j = 2 * hf + (z >> 1);                                  // field
-                            const bool odd = z & 1;
+                        for (int z = 0; z < RG; ++z) {
+                            const int j = (RG * g + z) >> 1;                                  // field
+                            const bool odd = (RG * g + z) & 1;
                             cc[z] = (int)(((odd ? cO : cE) >> (8 * j)) & 0xffu);
                             oo[z] = (int)(sbase + (((odd ? eO : eE) >> (8 * j)) & 0xffu));
                             sbase += ((odd ? tO : tE) >> (8 * j)) & 0xffu;
                         }
-                        T v[16];
+                        T v[RG * 4];
 #pragma unroll
-                        for (int z = 0; z < 4; ++z)
+                        for (int z = 0; z < RG; ++z)
 #pragma unroll
                             for (int k = 0; k < 4; ++k) v[4 * z + k] = prod[oo[z] + k];
 #pragma unroll
-                        for (int z = 0; z < 4; ++z) {
+                        for (int z = 0; z < RG; ++z) {
                             const int c = cc[z];
                             T sum = c > 0 ? v[4 * z] : (T)0;
                             sum += c > 1 ? v[4 * z + 1] : (T)0;
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
                             sum += c > 3 ? v[4 * z + 3] : (T)0;
                             if (c > 4)
                                 for (int k = 4; k < c; ++k) sum += prod[oo[z] + k];
-                            acc[8 * q + 4 * hf + z] += sum;
+                            acc[8 * q + RG * g + z] += sum;
                         }
                     }
                 }
