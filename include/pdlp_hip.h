@@ -83,7 +83,7 @@ typedef struct pdlp_problem {
  * three (float64) 32-bit words of 4-bit item counts (<= 15) of the thread's rows.  float32: rpt <= 40,
  * cap <= 16384; float64: rpt <= 24, cap <= 8192. */
 typedef struct pdlp_tiles {
-    int32_t lw, rpt, cap;       /* panel = 2^lw columns; rows per thread (even)       ; most items per tile  */
+    int32_t lw, rpt, cap;       /* panel = 2^lw columns; rows per thread              ; most items per tile  */
     int32_t nblk, npanel;       /* row blocks, column panels                                               */
     int32_t groups;             /* workgroups sharing a row block, each walking ceil(npanel/groups) panels; 1 = the
                                    epilogue is fused, > 1 (<= 8, <= npanel) = partial row sums + k_rowsum_epilogue */

@@ -90,9 +90,9 @@ def test_choose_rpt_fills_whole_rounds():
     # the bench matrix: 10M rows, 100 per row, 64K panels -> 0.655 items per (row, panel)
     rpt = choose_rpt(10_000_000, 1_000_000_000, 10_000_000, 16)
     nblk = -(-10_000_000 // (512 * rpt))
-    assert rpt % 2 == 0 and 512 * rpt * 0.6554 * 1.06 < 16384
+    assert 512 * rpt * 0.6554 * 1.06 < 16384
     assert nblk / (512 * -(-nblk // 512)) > 0.9
-    assert choose_rpt(1000, 3000, 1000, 16) >= 2
+    assert choose_rpt(1000, 3000, 1000, 16) >= 1
     assert choose_shape(10_000_000, 1_000_000_000, 10_000_000, 16) == (rpt, 1)
     # one rank's shard of the same problem on 8 GPUs: big row blocks, panels split over 8 workgroups
     rpt8, g8 = choose_shape(1_250_000, 125_000_000, 10_000_000, 16)

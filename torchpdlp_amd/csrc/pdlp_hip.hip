@@ -414,7 +414,7 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
                 constexpr int RG = sizeof(T) == 8 ? 2 : 4;      // rows advanced together (register budget)
 #pragma unroll
                 for (int g = 0; g < 8 / RG; ++g) {
-                    if (8 * q + RG * g < rpt) {         // rpt is even and counts of rows >= rpt are zero
+                    if (8 * q + RG * g < rpt) {         // counts of rows >= rpt are zero
                         int cc[RG], oo[RG];
 #pragma unroll
                         for (int z = 0; z < RG; ++z) {
@@ -1176,7 +1176,7 @@ int pdlp_attach_tiles(pdlp_handle h, int transpose, const pdlp_tiles* t)
     const int64_t rows = transpose ? h->nl : h->ml;
     const int rpt_max = h->p.dtype == PDLP_F32 ? TileCfg<float>::RPT_MAX : TileCfg<double>::RPT_MAX;
     const int cap_max = h->p.dtype == PDLP_F32 ? TileCfg<float>::CAP : TileCfg<double>::CAP;
-    if (t->rpt < 2 || t->rpt > rpt_max || (t->rpt & 1) || t->cap > cap_max || t->lw < 4 || t->lw > 16) return PDLP_ERR_INVALID;
+    if (t->rpt < 1 || t->rpt > rpt_max || t->cap > cap_max || t->lw < 4 || t->lw > 16) return PDLP_ERR_INVALID;
     const int64_t rb = (int64_t)TNT * t->rpt;
     if (t->nblk != (int)((rows + rb - 1) / rb) || t->npanel < 1) return PDLP_ERR_INVALID;
     if (t->groups < 1 || t->groups > h->rs_groups || t->groups > t->npanel) return PDLP_ERR_INVALID;

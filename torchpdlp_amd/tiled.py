@@ -95,11 +95,11 @@ def choose_shape(nrows: int, nnz: int, ncols: int, lw: int, cap: int = CAP, slot
     W = 1 << lw
     P = max(1, (ncols + W - 1) // W)
     per_row_panel = max(nnz / max(nrows, 1) * min(W, ncols) / max(ncols, 1), 1e-9)   # mean items of a row in a panel
-    best, best_score = (2, 1), -1.0
-    for rpt in range(2, rpt_max + 1, 2):
+    best, best_score = (1, 1), -1.0
+    for rpt in range(1, rpt_max + 1):
         rb = NT * rpt
         mean_tile = rb * per_row_panel
-        if mean_tile + 6.0 * mean_tile ** 0.5 > cap and rpt > 2:      # keep 6 sigma below the LDS capacity
+        if mean_tile + 6.0 * mean_tile ** 0.5 > cap and rpt > 1:      # keep 6 sigma below the LDS capacity
             break
         nblk = (nrows + rb - 1) // rb
         density = min(1.0, 0.35 + 0.65 * rpt / rpt_max)
@@ -143,8 +143,8 @@ def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, n
         rpt, g_auto = choose_shape(nrows, nnz, ncols, lw, cap, rpt_max=rpt_max)
         groups = g_auto if groups is None else groups
     groups = 1 if groups is None else int(groups)
-    if rpt % 2 or not 2 <= rpt <= rpt_max:
-        raise ValueError(f"rpt must be even and <= {rpt_max}")
+    if not 1 <= rpt <= rpt_max:
+        raise ValueError(f"rpt must be in 1..{rpt_max}")
     RB = NT * rpt
     P = max(1, (ncols + W - 1) // W)
     NB = max(1, (nrows + RB - 1) // RB)
