@@ -74,14 +74,15 @@ typedef struct pdlp_problem {
 } pdlp_problem;
 
 /* Optional panel-tiled copy of one of the two matrices (layout and builder: torchpdlp_amd/tiled.py).
- * Rows are cut into blocks of 512*rpt rows (one workgroup each; thread t owns rows t*rpt .. t*rpt+rpt-1 of
- * the block), columns into panels of 2^lw entries; a tile is (row block, panel).  Items of a tile are sorted
+ * Rows are cut into blocks of 512*rpt rows (one workgroup each; lane l of wave w owns rows w*64*rpt + i*64 + l,
+ * i < rpt, of the block), columns into panels of 2^lw entries; a tile is (row block, panel).  Items of a tile are sorted
  * by column; item = value + ((slot << lw) | local column), slot = rank of the item in row order inside the
  * tile; tiles are padded to multiples of 256 items with (value 0, slot = number of real items, column 0), and
  * every group of 256 sorted items is stored interleaved (position 4*lane + j holds sorted item 64*j + lane) so
  * that one wave's j-th gathers are 64 consecutive sorted items.  cnt holds, per (tile, thread), five (float32) or
- * three (float64) 32-bit words of 4-bit item counts (<= 15) of the thread's rows.  float32: rpt <= 40,
- * cap <= 16384; float64: rpt <= 24, cap <= 8192. */
+ * three (float64) 32-bit words of 4-bit item counts (<= 15) of the thread's rows (nibble i = row i of the thread);
+ * any 64 consecutive rows (one i of one wave) may hold at most 255 items of a tile -- the kernel scans the lanes'
+ * counts in 8-bit fields.  float32: rpt <= 40, cap <= 16384; float64: rpt <= 24, cap <= 8192. */
 typedef struct pdlp_tiles {
     int32_t lw, rpt, cap;       /* panel = 2^lw columns; rows per thread              ; most items per tile  */
     int32_t nblk, npanel;       /* row blocks, column panels                                               */

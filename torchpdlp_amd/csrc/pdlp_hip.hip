@@ -1056,7 +1056,7 @@ int read_last_rowptr(const int32_t* rp, int64_t rows, int64_t* nnz)
 // ================================================================================================
 extern "C" {
 
-int pdlp_abi_version(void) { return 1; }
+int pdlp_abi_version(void) { return 2; }   // 2: tile count words map lanes to wave-consecutive rows
 
 const char* pdlp_strerror(int code)
 {
