@@ -195,6 +195,7 @@ template <typename T, bool UNSCALE> struct KktPrimalEpi {
 // ------------------------------------------------------------------------------------------------
 template <typename T, class Epi>
 __global__ __launch_bounds__(BLOCK) void k_csr_fused(const int32_t* __restrict__ blk, int nblk,
+                                                     const int32_t* __restrict__ lch, int nchunks, T* __restrict__ longpart,
                                                      const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
                                                      const T* __restrict__ va, const T* __restrict__ vin, Epi epi,
                                                      double* __restrict__ partials)
@@ -206,7 +207,20 @@ __global__ __launch_bounds__(BLOCK) void k_csr_fused(const int32_t* __restrict__
     epi.load();
     double acc[NACC] = {0.0, 0.0, 0.0, 0.0};
 
-    for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
+    for (int b = blockIdx.x; b < nblk + nchunks; b += gridDim.x) {
+        if (b >= nblk) {
+            // one NNZ_CAP-sized chunk of a row too long for the LDS staging: its partial sum goes to longpart[chunk];
+            // k_long_rows adds a row's chunks in order and runs the epilogue (dense columns of real LPs put
+            // 1e5+ entries into single rows of K' -- one workgroup per row would serialise the whole product)
+            const int c = b - nblk;
+            const int a = lch[2 * c], e = lch[2 * c + 1];
+            T s = (T)0;
+            for (int i = a + tid; i < e; i += BLOCK) s += va[i] * vin[ci[i]];
+            s = block_sum(s, tred);
+            if (tid == 0) longpart[c] = s;
+            __syncthreads();
+            continue;
+        }
         const int r0 = blk[b], r1 = blk[b + 1];
         const int a = rp[r0], e = rp[r1];
         const int nn = e - a, nrows = r1 - r0;
@@ -231,20 +245,35 @@ __global__ __launch_bounds__(BLOCK) void k_csr_fused(const int32_t* __restrict__
             for (int off = tpr >> 1; off > 0; off >>= 1) s += shfl_xor_t(s, off);
             if (lr < nrows && lt == 0) epi(row, s, acc);
             __syncthreads();
-        } else {
-            // one long row: the whole workgroup strides over it
-            T s = (T)0;
-            for (int i = a + tid; i < e; i += BLOCK) s += va[i] * vin[ci[i]];
-            s = block_sum(s, tred);
-            if (tid == 0) epi(r0, s, acc);
-            __syncthreads();
-        }
+        }       // (a single row longer than NNZ_CAP is covered by chunks, see above)
     }
     if (Epi::NA > 0) {
 #pragma unroll
         for (int r = 0; r < Epi::NA; ++r) {
             const double v = block_sum(acc[r], dred);
             if (tid == 0) partials[(size_t)blockIdx.x * NACC + r] = v;
+        }
+    }
+}
+
+// epilogue of the rows that k_csr_fused handled in chunks: chunk sums added in fixed order
+template <typename T, class Epi>
+__global__ __launch_bounds__(BLOCK) void k_long_rows(const int32_t* __restrict__ lrow, const int32_t* __restrict__ lptr, int nlong,
+                                                     const T* __restrict__ longpart, Epi epi, double* __restrict__ partials)
+{
+    __shared__ double dred[4];
+    epi.load();
+    double acc[NACC] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nlong; i += gridDim.x * BLOCK) {
+        T s = (T)0;
+        for (int c = lptr[i]; c < lptr[i + 1]; ++c) s += longpart[c];
+        epi(lrow[i], s, acc);
+    }
+    if (Epi::NA > 0) {
+#pragma unroll
+        for (int r = 0; r < Epi::NA; ++r) {
+            const double v = block_sum(acc[r], dred);
+            if (threadIdx.x == 0) partials[(size_t)blockIdx.x * NACC + r] = v;
         }
     }
 }
@@ -750,6 +779,12 @@ struct Schedule {
     int32_t* blk = nullptr;   // device, nblk+1 row starts
     int nblk = 0;
     int grid = 0;
+    // rows longer than NNZ_CAP, cut into chunks of NNZ_CAP non-zeros
+    int32_t* lch = nullptr;   // device, [2*nchunks] (first, end) non-zero of every chunk
+    int32_t* lrow = nullptr;  // device, [nlong] the rows
+    int32_t* lptr = nullptr;  // device, [nlong+1] their chunk ranges
+    void* longpart = nullptr; // device, [nchunks] chunk sums
+    int nchunks = 0, nlong = 0, lgrid = 0;
     // panel-tiled copy (optional, attached by the caller): used instead of the CSR arrays when set
     bool tiled = false;
     pdlp_tiles t{};
@@ -760,6 +795,28 @@ inline int grid_for(int64_t n) { int64_t g = (n + BLOCK - 1) / BLOCK; return (in
 
 // upper bound on the number of row blocks: two consecutive blocks together exceed a cap
 inline int64_t max_blocks(int64_t rows, int64_t nnz) { return 2 * (rows / ROWS_CAP + nnz / NNZ_CAP) + 4; }
+
+// upper bounds on the chunks / long rows of a matrix with nnz non-zeros
+inline int64_t max_chunks(int64_t nnz) { return 2 * (nnz / NNZ_CAP) + 2; }
+inline int64_t max_long(int64_t nnz) { return nnz / NNZ_CAP + 1; }
+constexpr int LONG_GRID = 64;
+
+void build_long_rows_host(const std::vector<int32_t>& rp, int64_t rows, std::vector<int32_t>& lch, std::vector<int32_t>& lrow,
+                          std::vector<int32_t>& lptr)
+{
+    lch.clear(); lrow.clear(); lptr.clear();
+    lptr.push_back(0);
+    for (int64_t r = 0; r < rows; ++r) {
+        const int64_t a = rp[r], e = rp[r + 1];
+        if (e - a <= NNZ_CAP) continue;
+        for (int64_t c = a; c < e; c += NNZ_CAP) {
+            lch.push_back((int32_t)c);
+            lch.push_back((int32_t)(c + NNZ_CAP < e ? c + NNZ_CAP : e));
+        }
+        lrow.push_back((int32_t)r);
+        lptr.push_back((int32_t)(lch.size() / 2));
+    }
+}
 
 void build_schedule_host(const std::vector<int32_t>& rp, int64_t rows, std::vector<int32_t>& out)
 {
@@ -775,7 +832,7 @@ void build_schedule_host(const std::vector<int32_t>& rp, int64_t rows, std::vect
             nnz += len;
             ++e;
         }
-        if (e == r) e = r + 1;   // a single row longer than NNZ_CAP: whole-workgroup path
+        if (e == r) e = r + 1;   // a single row longer than NNZ_CAP: its own (skipped) block, done in chunks
         out.push_back((int32_t)e);
         r = e;
     }
@@ -831,8 +888,11 @@ int launch_csr(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* 
     const int32_t* rp = transpose ? h->p.KT_rowptr : h->p.K_rowptr;
     const int32_t* ci = transpose ? h->p.KT_colidx : h->p.K_colidx;
     const T* va = (const T*)(transpose ? h->p.KT_val : h->p.K_val);
-    hipLaunchKernelGGL((k_csr_fused<T, Epi>), dim3(s.grid), dim3(BLOCK), 0, h->stream, s.blk, s.nblk, rp, ci, va,
-                       (const T*)vin, epi, partials);
+    hipLaunchKernelGGL((k_csr_fused<T, Epi>), dim3(s.grid), dim3(BLOCK), 0, h->stream, s.blk, s.nblk, s.lch, s.nchunks,
+                       (T*)s.longpart, rp, ci, va, (const T*)vin, epi, partials);
+    if (s.nlong > 0)
+        hipLaunchKernelGGL((k_long_rows<T, Epi>), dim3(s.lgrid), dim3(BLOCK), 0, h->stream, s.lrow, s.lptr, s.nlong,
+                           (const T*)s.longpart, epi, partials + (size_t)s.grid * NACC);
     HIP_TRY(hipGetLastError());
     return PDLP_OK;
 }
@@ -840,7 +900,7 @@ int launch_csr(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* 
 inline int grid_of(const Schedule& s, int64_t rows)
 {
     if (s.nblk == 0) return 0;
-    if (!s.tiled) return s.grid;
+    if (!s.tiled) return s.grid + (s.nlong > 0 ? s.lgrid : 0);
     return s.t.groups == 1 ? s.t.nblk : grid_for(rows);      // split tiles: the partial sums come from k_rowsum_epilogue
 }
 
@@ -1016,7 +1076,7 @@ struct Carve {
 };
 
 // one layout function used by both the size query and pdlp_create
-int64_t layout(const pdlp_problem* p, int64_t nnzK, int64_t nnzKT, int64_t* offs /*[24]*/)
+int64_t layout(const pdlp_problem* p, int64_t nnzK, int64_t nnzKT, int64_t* offs /*[32]*/)
 {
     const int64_t es = p->dtype == PDLP_F32 ? 4 : 8;
     const int64_t nl = p->col1 - p->col0, ml = p->row1 - p->row0;
@@ -1030,7 +1090,7 @@ int64_t layout(const pdlp_problem* p, int64_t nnzK, int64_t nnzKT, int64_t* offs
     offs[k++] = c.take(nl * es);                                  // 9     x_last
     offs[k++] = c.take(ml * es);                                  // 10    y_last
     for (int i = 0; i < 3; ++i) offs[k++] = c.take(ml * es);     // 11..13 kx caches
-    const int64_t pgrid = MAX_GRID + (nl > ml ? nl : ml) / (TNT * 2) + 1;  // CSR grid, or one workgroup per >= 2048 rows (tiled)
+    const int64_t pgrid = MAX_GRID + LONG_GRID + (nl > ml ? nl : ml) / (TNT * 2) + 1;  // CSR grid (+ long rows), or one workgroup per >= 512 rows (tiled)
     offs[k++] = c.take(pgrid * NACC * 8);                         // 14    partA
     offs[k++] = c.take(pgrid * NACC * 8);                         // 15    partB
     offs[k++] = c.take(PDLP_NRED * 8);                            // 16    red
@@ -1038,6 +1098,13 @@ int64_t layout(const pdlp_problem* p, int64_t nnzK, int64_t nnzKT, int64_t* offs
     offs[k++] = c.take((max_blocks(ml, nnzK) + 1) * 4);           // 18    schedule K
     offs[k++] = c.take((max_blocks(nl, nnzKT) + 1) * 4);          // 19    schedule K'
     offs[k++] = c.take(rowsum_groups(nl > ml ? nl : ml) * ((nl > ml ? nl : ml) + (int64_t)TNT * TRPT_MAX_ANY) * es);   // 20  rowsum scratch
+    for (int t = 0; t < 2; ++t) {                                 // 21..28 long rows of K, then of K'
+        const int64_t nnz = t == 0 ? nnzK : nnzKT;
+        offs[k++] = c.take(max_chunks(nnz) * 2 * 4);              //   chunk (first, end)
+        offs[k++] = c.take(max_long(nnz) * 4);                    //   rows
+        offs[k++] = c.take((max_long(nnz) + 1) * 4);              //   chunk ranges
+        offs[k++] = c.take(max_chunks(nnz) * es);                 //   chunk sums
+    }
     return c.off;
 }
 
@@ -1076,7 +1143,7 @@ int pdlp_workspace_bytes(const pdlp_problem* p, int64_t* bytes)
     int rc = check_problem(p);
     if (rc != PDLP_OK || !bytes) return PDLP_ERR_INVALID;
     HIP_TRY(hipSetDevice(p->device));
-    int64_t nnzK = 0, nnzKT = 0, offs[24];
+    int64_t nnzK = 0, nnzKT = 0, offs[32];
     if ((rc = read_last_rowptr(p->K_rowptr, p->row1 - p->row0, &nnzK)) != PDLP_OK) return rc;
     if ((rc = read_last_rowptr(p->KT_rowptr, p->col1 - p->col0, &nnzKT)) != PDLP_OK) return rc;
     *bytes = layout(p, nnzK, nnzKT, offs);
@@ -1093,7 +1160,7 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     if (ml > 0) HIP_TRY(hipMemcpy(rpK.data(), p->K_rowptr, (size_t)(ml + 1) * 4, hipMemcpyDeviceToHost));
     if (nl > 0) HIP_TRY(hipMemcpy(rpKT.data(), p->KT_rowptr, (size_t)(nl + 1) * 4, hipMemcpyDeviceToHost));
     if (rpK[0] != 0 || rpKT[0] != 0) return PDLP_ERR_INVALID;
-    int64_t offs[24];
+    int64_t offs[32];
     const int64_t need = layout(p, rpK[ml], rpKT[nl], offs);
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255u)) return PDLP_ERR_WORKSPACE;
 
@@ -1132,6 +1199,24 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     h->sKT.grid = h->sKT.nblk < MAX_GRID ? h->sKT.nblk : MAX_GRID;
     if (rc == PDLP_OK && hipMemcpy(h->sKT.blk, sched.data(), sched.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
         rc = PDLP_ERR_HIP_BASE - 1;
+    // rows longer than NNZ_CAP
+    for (int t = 0; t < 2 && rc == PDLP_OK; ++t) {
+        Schedule& sc = t == 0 ? h->sK : h->sKT;
+        std::vector<int32_t> lch, lrow, lptr;
+        build_long_rows_host(t == 0 ? rpK : rpKT, t == 0 ? ml : nl, lch, lrow, lptr);
+        sc.lch = (int32_t*)(w + offs[21 + 4 * t]); sc.lrow = (int32_t*)(w + offs[22 + 4 * t]);
+        sc.lptr = (int32_t*)(w + offs[23 + 4 * t]); sc.longpart = (void*)(w + offs[24 + 4 * t]);
+        sc.nchunks = (int)(lch.size() / 2); sc.nlong = (int)lrow.size();
+        sc.lgrid = sc.nlong > 0 ? (int)((sc.nlong + BLOCK - 1) / BLOCK < LONG_GRID ? (sc.nlong + BLOCK - 1) / BLOCK : LONG_GRID) : 0;
+        const int64_t work = (int64_t)sc.nblk + sc.nchunks;
+        sc.grid = (int)(work < MAX_GRID ? work : MAX_GRID);
+        if (sc.nlong > 0) {
+            if (hipMemcpy(sc.lch, lch.data(), lch.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(sc.lrow, lrow.data(), lrow.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(sc.lptr, lptr.data(), lptr.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+                rc = PDLP_ERR_HIP_BASE - 1;
+        }
+    }
     // zero every state vector, scratch and scalar (everything in front of the schedules)
     if (rc == PDLP_OK && hipMemsetAsync(w, 0, (size_t)offs[18], h->stream) != hipSuccess) rc = PDLP_ERR_HIP_BASE - 1;
     if (rc != PDLP_OK) { delete h; return rc; }
