@@ -675,3 +675,31 @@ def test_runs_are_bitwise_reproducible(monkeypatch):
             outs.append((x.clone(), y.clone(), e.scalars()["eta"], e.kkt(N.CUR, 1.1)["kkt"]))
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
         assert outs[0][2] == outs[1][2] and outs[0][3] == outs[1][3]
+
+
+def test_graph_replay_is_bitwise_the_direct_launch_loop(monkeypatch):
+    """PDLP_GRAPH=1: pdlp_iterate replays captured pairs of iterations as hipGraph launches from the library's
+    own stream; same kernels in the same order, so the iterates and scalars must be identical to the direct loop"""
+    lp = gen_lp(20_000, 15_000, 6, seed=21, device=DEV, recipe="mixed")
+    K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
+    outs = []
+    for graph in (False, True):
+        if graph:
+            monkeypatch.setenv("PDLP_GRAPH", "1")
+        else:
+            monkeypatch.delenv("PDLP_GRAPH", raising=False)
+        eng = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
+        res = []
+        for adaptive in (True, False):
+            eng.set_iterate(torch.zeros(lp.n, device=DEV), torch.zeros(lp.m, device=DEV))
+            eng.set_step(0.02, 1.3, 1.0, 0)
+            eng.iterate(23, adaptive)                # 1 direct (K x cache) + 11 replays, or 11 replays + 1 direct
+            eng.iterate(8, adaptive)                 # roles differ from the first capture when the count was odd
+            x, y = eng.get_iterate(N.CUR)
+            sc = eng.scalars()
+            res.append((x.cpu().numpy(), y.cpu().numpy(), sc["eta"], sc["eta_sum"], sc["k"]))
+        outs.append(res)
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+        assert a[2:] == b[2:]

@@ -17,6 +17,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -859,9 +860,33 @@ struct pdlp_solver {
     int64_t rs_stride;            // rows + one row block
     int rs_groups;                // panel groups the scratch has room for
     int last_gridA, last_gridB;   // grids of the last primal / dual launch (adaptive reduce)
+    // optional (PDLP_GRAPH=1): pdlp_iterate replays two captured iterations (the buffer roles return after two) as one
+    // hipGraph launch.  Captured on and replayed from the library's own stream (capture is not allowed on the
+    // legacy null stream), ordered against the caller's stream with events.  One graph per (roles, mode).
+    hipStream_t gstream;
+    hipEvent_t ev_in, ev_out;
+    bool graph_ok;
+    struct IterGraph { bool valid; int ix_cur, ix_prev, adaptive; hipGraphExec_t exec; } graphs[12];
 };
 
 namespace {
+
+void drop_graphs(pdlp_handle h)
+{
+    for (auto& g : h->graphs) {
+        if (g.valid) (void)hipGraphExecDestroy(g.exec);
+        g.valid = false;
+    }
+}
+
+void free_handle(pdlp_handle h)
+{
+    drop_graphs(h);
+    if (h->gstream) { (void)hipStreamSynchronize(h->gstream); (void)hipStreamDestroy(h->gstream); }
+    if (h->ev_in) (void)hipEventDestroy(h->ev_in);
+    if (h->ev_out) (void)hipEventDestroy(h->ev_out);
+    delete h;
+}
 
 template <typename T, class Epi>
 int launch_csr(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* partials)
@@ -1188,6 +1213,15 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     h->rs_groups = (int)rowsum_groups(nl > ml ? nl : ml);
     h->kx_valid = false; h->cand_valid[0] = h->cand_valid[1] = false;
     h->last_gridA = h->last_gridB = 0;
+    for (auto& g : h->graphs) g.valid = false;
+    h->gstream = nullptr; h->ev_in = h->ev_out = nullptr;
+    // opt-in (PDLP_GRAPH=1): on ROCm 7.2 / MI355X the replay measured 6-12 % SLOWER than direct launches on the small
+    // LPs it was meant for (neos3-shaped: 17.8k vs 20.2k it/s; 1M x 1M, 5 nnz/row: 10.25k vs 10.86k it/s) -- the loop is
+    // bound by dependent-kernel latency on the device, not by host launch cost -- and makes no difference on large ones
+    h->graph_ok = std::getenv("PDLP_GRAPH") != nullptr &&
+                  hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) == hipSuccess;
 
     std::vector<int32_t> sched;
     build_schedule_host(rpK, ml, sched);
@@ -1219,7 +1253,7 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     }
     // zero every state vector, scratch and scalar (everything in front of the schedules)
     if (rc == PDLP_OK && hipMemsetAsync(w, 0, (size_t)offs[18], h->stream) != hipSuccess) rc = PDLP_ERR_HIP_BASE - 1;
-    if (rc != PDLP_OK) { delete h; return rc; }
+    if (rc != PDLP_OK) { free_handle(h); return rc; }
     if (p->dtype == PDLP_F32) hipLaunchKernelGGL(k_set_step<float>, dim3(1), dim3(1), 0, h->stream, h->sc, 0.0, 1.0, 1.0, 0.0);
     else hipLaunchKernelGGL(k_set_step<double>, dim3(1), dim3(1), 0, h->stream, h->sc, 0.0, 1.0, 1.0, 0.0);
     *out = h;
@@ -1230,7 +1264,7 @@ void pdlp_destroy(pdlp_handle h)
 {
     if (!h) return;
     (void)hipStreamSynchronize(h->stream);
-    delete h;
+    free_handle(h);
 }
 
 int pdlp_buffer_ptr(pdlp_handle h, int which, void** ptr)
@@ -1257,6 +1291,7 @@ int pdlp_attach_tiles(pdlp_handle h, int transpose, const pdlp_tiles* t)
 {
     if (!h) return PDLP_ERR_INVALID;
     Schedule& s = transpose ? h->sKT : h->sK;
+    drop_graphs(h);               // captured launches name the old kernel and arrays
     if (!t) { s.tiled = false; return PDLP_OK; }
     const int64_t rows = transpose ? h->nl : h->ml;
     const int rpt_max = h->p.dtype == PDLP_F32 ? TileCfg<float>::RPT_MAX : TileCfg<double>::RPT_MAX;
@@ -1362,10 +1397,10 @@ int pdlp_adaptive_update(pdlp_handle h)
     return PDLP_OK;
 }
 
-int pdlp_iterate(pdlp_handle h, int iters, int adaptive)
+namespace {
+
+int iterate_direct(pdlp_handle h, int iters, int adaptive)
 {
-    if (!h || iters < 0) return PDLP_ERR_INVALID;
-    if (h->nl != h->p.n || h->ml != h->p.m) return PDLP_ERR_STATE;   // sharded problems need the caller's exchange
     int rc;
     for (int it = 0; it < iters; ++it) {
         if ((rc = pdlp_primal_half(h, adaptive)) != PDLP_OK) return rc;
@@ -1379,6 +1414,73 @@ int pdlp_iterate(pdlp_handle h, int iters, int adaptive)
                                    h->partB, h->last_gridB, h->red, h->sc, 1);
         }
     }
+    HIP_TRY(hipGetLastError());
+    return PDLP_OK;
+}
+
+// the executable graph of two iterations from the current buffer roles (captured on first use), or nullptr
+pdlp_solver::IterGraph* pair_graph(pdlp_handle h, int adaptive)
+{
+    pdlp_solver::IterGraph* slot = nullptr;
+    for (auto& g : h->graphs) {
+        if (g.valid && g.ix_cur == h->ix_cur && g.ix_prev == h->ix_prev && g.adaptive == adaptive) return &g;
+        if (!g.valid && !slot) slot = &g;
+    }
+    if (!slot) return nullptr;
+    // capture: the launch code runs unchanged against the library's stream; host-side roles are put back afterwards
+    const int ix_cur = h->ix_cur, ix_prev = h->ix_prev, gA = h->last_gridA, gB = h->last_gridB;
+    const bool kxv = h->kx_valid, c0 = h->cand_valid[0], c1 = h->cand_valid[1];
+    hipStream_t user = h->stream;
+    if (hipStreamBeginCapture(h->gstream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        h->graph_ok = false;
+        return nullptr;
+    }
+    h->stream = h->gstream;
+    const int rc = iterate_direct(h, 2, adaptive);
+    h->stream = user;
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(h->gstream, &graph);
+    h->ix_cur = ix_cur; h->ix_prev = ix_prev; h->last_gridA = gA; h->last_gridB = gB;
+    h->kx_valid = kxv; h->cand_valid[0] = c0; h->cand_valid[1] = c1;
+    if (rc != PDLP_OK || e != hipSuccess || !graph ||
+        hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        h->graph_ok = false;
+        return nullptr;
+    }
+    (void)hipGraphDestroy(graph);
+    slot->valid = true; slot->ix_cur = ix_cur; slot->ix_prev = ix_prev; slot->adaptive = adaptive;
+    return slot;
+}
+
+}  // namespace
+
+int pdlp_iterate(pdlp_handle h, int iters, int adaptive)
+{
+    if (!h || iters < 0) return PDLP_ERR_INVALID;
+    if (h->nl != h->p.n || h->ml != h->p.m) return PDLP_ERR_STATE;   // sharded problems need the caller's exchange
+    adaptive = adaptive ? 1 : 0;
+    int rc, left = iters;
+    if (h->graph_ok && left >= 5) {
+        if (adaptive && !h->kx_valid) {          // the first adaptive iteration after a reset also refreshes the K x cache
+            if ((rc = iterate_direct(h, 1, adaptive)) != PDLP_OK) return rc;
+            --left;
+        }
+        pdlp_solver::IterGraph* g = pair_graph(h, adaptive);
+        if (g) {
+            HIP_TRY(hipEventRecord(h->ev_in, h->stream));
+            HIP_TRY(hipStreamWaitEvent(h->gstream, h->ev_in, 0));
+            for (; left >= 2; left -= 2) HIP_TRY(hipGraphLaunch(g->exec, h->gstream));
+            HIP_TRY(hipEventRecord(h->ev_out, h->gstream));
+            HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_out, 0));
+            h->cand_valid[0] = h->cand_valid[1] = false;     // (what two direct iterations leave behind)
+            if (!adaptive) h->kx_valid = false;
+            if (adaptive) { h->last_gridA = grid_of(h->sKT, h->nl); h->last_gridB = grid_of(h->sK, h->ml); }
+        }
+    }
+    if ((rc = iterate_direct(h, left, adaptive)) != PDLP_OK) return rc;
     if (!adaptive && iters > 0) {
         if (h->p.dtype == PDLP_F32) hipLaunchKernelGGL(k_fixed_advance<float>, dim3(1), dim3(1), 0, h->stream, h->sc, iters);
         else hipLaunchKernelGGL(k_fixed_advance<double>, dim3(1), dim3(1), 0, h->stream, h->sc, iters);
