@@ -137,6 +137,18 @@ int pdlp_primal_half(pdlp_handle h, int adaptive);
  * CSR(K) SpMV with the projection and sums fused.  Needs xbar complete over [0,n).  Afterwards
  * the new iterate becomes PDLP_CUR and the old one PDLP_PREV (pdhg.py:77-78). */
 int pdlp_dual_half(pdlp_handle h, int adaptive);
+/* Sharded problems, optional: start the coming half-step's product on the panels that lie wholly inside THIS rank's
+ * block of the gathered vector (the block the preceding half-step just wrote) on a library-owned side stream, so
+ * that it overlaps the all-gather of the other ranks' blocks.  Call right after the half-step that produced the
+ * block and before the all-gather; the matching pdlp_primal_half / pdlp_dual_half then multiplies the remaining
+ * panels, adds the partial row sums in fixed order and runs the fused update.  No-ops (return PDLP_OK) when the
+ * matrix is not tiled, the problem is not sharded, or (dual, adaptive) the K x cache has to be refreshed first.
+ * The reference has no counterpart (single device); the result equals the unsplit product up to summation order. */
+int pdlp_primal_half_begin(pdlp_handle h);
+int pdlp_dual_half_begin(pdlp_handle h, int adaptive);
+/* what the two calls above will do for K (transpose = 0) or K' (1): out = {first local panel, end of the local panels,
+ * panel groups of the local panels, panel groups of the others}; all zero = the product is not split */
+int pdlp_split_info(pdlp_handle h, int transpose, int32_t out[4]);
 /* adaptive rule, part 1: reduce this rank's ||dx||^2, ||dy||^2, dy'K dx into PDLP_BUF_RED[0..2]
  * (all-reduce them across ranks before part 2) -- step.py:91-96 */
 int pdlp_adaptive_reduce(pdlp_handle h);

@@ -168,3 +168,66 @@ def test_two_ranks_on_one_gpu_match_single_rank():
         ret = man.dict()
         mp.spawn(_gpu_worker, args=(world, port, ret), nprocs=world, join=True)
         assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def _gpu_split_worker(rank, world, port, ret):
+    """two ranks, tiled kernels forced, a problem wide enough for several 64K-column panels per rank: the products
+    are split (local panels on the side stream before the all-gather, the others after it)"""
+    os.environ["PDLP_TILED"] = "1"
+    import torchpdlp_amd as tp
+    from torchpdlp_amd import _native as N
+    from torchpdlp_amd.distributed import gather_solution, shard_engine
+    from torchpdlp_amd.synthetic import gen_lp
+    _init(rank, world, port)
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        lp = gen_lp(330_000, 300_000, 4, seed=12, device=dev, recipe="mixed")
+        K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
+        comm = tp.Comm()
+        eng = shard_engine(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq, comm)
+        assert all(t is not None for t in eng.tiles)
+        for tr in (0, 1):
+            info = eng.split_info(tr)
+            assert info["local_groups"] >= 1 and info["other_groups"] >= 1, info
+            assert info["local_panels"][1] - info["local_panels"][0] >= 1
+        res = {}
+        for adaptive in (True, False):
+            g = torch.Generator().manual_seed(3)
+            x0 = torch.randn(eng.n, generator=g).to(dev)
+            y0 = torch.randn(eng.m, generator=g).to(dev)
+            x0[lp.n:] = 0
+            y0[lp.m:] = 0
+            eng.set_iterate(x0[eng.cols[0]:eng.cols[1]], y0[eng.rows[0]:eng.rows[1]])
+            eng.set_step(0.02, 1.1, 1.0, 0)
+            eng.iterate(9, adaptive)
+            eng.iterate(4, adaptive)
+            x, y = eng.get_iterate(N.CUR)
+            kkt = eng.kkt(N.CUR, 1.0)
+            res[adaptive] = (gather_solution(eng, x, lp.n).cpu(), eng.scalars()["eta"], kkt["kkt"], x0[:lp.n].cpu(), y0[:lp.m].cpu())
+        del eng
+        if rank == 0:
+            os.environ["PDLP_TILED"] = "0"
+            e1 = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
+            for adaptive in (True, False):
+                xs, eta, kkt, x0, y0 = res[adaptive]
+                e1.set_iterate(x0.to(dev), y0.to(dev))
+                e1.set_step(0.02, 1.1, 1.0, 0)
+                e1.iterate(13, adaptive)
+                x1, _ = e1.get_iterate(N.CUR)
+                np.testing.assert_allclose(xs.numpy(), x1.cpu().numpy(), rtol=2e-4, atol=2e-5)
+                np.testing.assert_allclose(eta, e1.scalars()["eta"], rtol=1e-4)
+                np.testing.assert_allclose(kkt, e1.kkt(N.CUR, 1.0)["kkt"], rtol=1e-4)
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_split_products_match_single_rank():
+    world = 2
+    port = _free_port()
+    with mp.Manager() as man:
+        ret = man.dict()
+        mp.spawn(_gpu_split_worker, args=(world, port, ret), nprocs=world, join=True)
+        assert dict(ret) == {0: "ok", 1: "ok"}

@@ -14,7 +14,20 @@ ruiz = len(sys.argv) > 4 and sys.argv[4] == "1"
 max_kkt = int(sys.argv[5]) if len(sys.argv) > 5 else 40000
 dt = torch.float64 if (len(sys.argv) > 6 and sys.argv[6] == "f64") else torch.float32
 dev = torch.device("cuda", 0)
+time_limit = float(os.environ.get("TIME_LIMIT", "900"))
+
+
+def _heartbeat():           # long restart periods print nothing for minutes; the GPU runner wants to see progress
+    import threading
+    def beat():
+        while True:
+            time.sleep(60)
+            print(f"[heartbeat] {time.time() - t0:.0f}s", flush=True)
+    threading.Thread(target=beat, daemon=True).start()
+
+
 t0 = time.time()
+_heartbeat()
 lp = tp.gen_lp(n, n, k, seed=0, device=dev, dtype=dt)
 K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
 c, q, l, u = lp.c, lp.q, lp.l, lp.u
@@ -28,6 +41,6 @@ torch.cuda.synchronize()
 print(f"setup {time.time()-t0:.1f}s (ruiz {t_ruiz:.2f}s) tiles={[t is not None for t in eng.tiles]}", flush=True)
 trace = dict(kkt=[], omega=[], restarts=[])
 x, obj, it, nr, j, status, secs = run_pdlp(eng, max_kkt=max_kkt, tol=tol, verbose=True, precondition=ruiz, primal_update=True,
-                                           adaptive=True, time_limit=900, seed=0, power_iters=100, trace=trace)
+                                           adaptive=True, time_limit=time_limit, seed=0, power_iters=100, trace=trace)
 print(f"RESULT n={n} k={k} tol={tol} ruiz={ruiz} dtype={dt}: status={status} obj={obj:.6f} iterations={it} restarts={nr} kkt_passes={j} "
       f"solve_time={secs:.2f}s  ({it/secs:.1f} it/s incl. power iteration and checks)", flush=True)

@@ -55,6 +55,9 @@ SIGNATURES = {
     "pdlp_get_scalars": (_I, [_H, C.POINTER(_D)]),
     "pdlp_primal_half": (_I, [_H, _I]),
     "pdlp_dual_half": (_I, [_H, _I]),
+    "pdlp_primal_half_begin": (_I, [_H]),
+    "pdlp_dual_half_begin": (_I, [_H, _I]),
+    "pdlp_split_info": (_I, [_H, _I, C.POINTER(C.c_int32)]),
     "pdlp_adaptive_reduce": (_I, [_H]),
     "pdlp_adaptive_update": (_I, [_H]),
     "pdlp_iterate": (_I, [_H, _I, _I]),

@@ -312,6 +312,7 @@ template <typename T, class Epi, bool FUSED>
 __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restrict__ tidx, const T* __restrict__ tval,
                                                         const int32_t* __restrict__ tile_ptr, const uint32_t* __restrict__ tcnt,
                                                         int npanel, int lw, int rpt, int nrows, int nblk, int ppg,
+                                                        int vtotal, int skip_lo, int skip_len, int slot0,
                                                         const T* __restrict__ vin, T* __restrict__ rowsum,
                                                         int64_t rs_stride, Epi epi, double* __restrict__ partials)
 {
@@ -324,7 +325,11 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = FUSED ? blockIdx.x : blockIdx.x % nblk;
     const int grp = FUSED ? 0 : blockIdx.x / nblk;
-    const int p_lo = grp * ppg, p_hi = (p_lo + ppg < npanel) ? p_lo + ppg : npanel;
+    // A launch walks `vtotal` panels in "virtual" order: panel = v below skip_lo, v + skip_len from there on.  That
+    // lets one launch cover just the panels of the locally owned block of the gathered vector and another one all the
+    // others (sharded problems: the first runs while the all-gather of the vector is still in flight).
+    const int p_lo = grp * ppg, p_hi = (p_lo + ppg < vtotal) ? p_lo + ppg : vtotal;
+    auto pmap = [&](int v) { return v < skip_lo ? v : v + skip_len; };
     const uint32_t mask = (1u << lw) - 1u;
     if (FUSED) epi.load();
     T acc[TRPT_MAX];
@@ -378,11 +383,11 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
         }
     };
     const size_t tile0 = (size_t)b * npanel;
-    const bool has_panels = p_lo < npanel;             // (pdlp_attach_tiles rejects group counts that leave a group empty)
+    const bool has_panels = p_lo < vtotal;             // (the host never launches a group without panels)
     u32x4 pk[TU];
     V4 vv[TU];
-    int i0 = has_panels ? tile_ptr[tile0 + p_lo] : 0;
-    int i1 = has_panels ? tile_ptr[tile0 + p_lo + 1] : 0;
+    int i0 = has_panels ? tile_ptr[tile0 + pmap(p_lo)] : 0;
+    int i1 = has_panels ? tile_ptr[tile0 + pmap(p_lo) + 1] : 0;
     load_into(pk, vv, i0, i1);
 
 #ifdef PDLP_STAMPS     /* diagnostic build (tools/ablate_tiled.sh): where a tile's cycles go; never shipped */
@@ -392,10 +397,16 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
 #else
 #define STAMP(acc) do { } while (0)
 #endif
-    for (int p = p_lo; p < p_hi; ++p) {
+    for (int v = p_lo; v < p_hi; ++v) {
+        const int p = pmap(v);
         const size_t tile = tile0 + p;
         const T* __restrict__ xin = vin + ((size_t)p << lw);
-        const int i0n = i1, i1n = p + 1 < p_hi ? tile_ptr[tile + 2] : i1;       // the next tile (empty after the last)
+        int i0n = i1, i1n = i1;                                                  // the next tile (empty after the last)
+        if (v + 1 < p_hi) {
+            const int pn = pmap(v + 1);
+            i0n = tile_ptr[tile0 + pn];
+            i1n = tile_ptr[tile0 + pn + 1];
+        }
         // segment lengths (4 bits each) of this thread's rows: row i of lane l of wave w is row w*64*rpt + i*64 + l
         // of the row block, so the 64 lanes of a wave sit on 64 consecutive rows for every i
         uint32_t cw[TCW];
@@ -493,7 +504,7 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
     const int rb = TNT * rpt;
     const int row0 = b * rb + wv * 64 * rpt + lane;
     if (!FUSED) {
-        T* __restrict__ rs = rowsum + (size_t)grp * rs_stride;
+        T* __restrict__ rs = rowsum + (size_t)(slot0 + grp) * rs_stride;
 #pragma unroll
         for (int r = 0; r < TRPT_MAX; ++r)
             if (r < rpt && row0 + 64 * r < nrows) rs[row0 + 64 * r] = acc[r];
@@ -789,6 +800,11 @@ struct Schedule {
     // panel-tiled copy (optional, attached by the caller): used instead of the CSR arrays when set
     bool tiled = false;
     pdlp_tiles t{};
+    // sharded problems: the panels lying wholly inside the locally owned block of the gathered vector, [loc_pa, loc_pb),
+    // can be multiplied before the all-gather of that vector has finished (pdlp_*_half_begin)
+    int loc_pa = 0, loc_pb = 0;
+    int slotsA = 0, slotsB = 0;   // panel groups (= partial row sum slots) of the local and of the other panels
+    bool pending = false;         // the local panels of the next product are already in rowsum[0 .. slotsA)
 };
 
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
@@ -860,6 +876,7 @@ struct pdlp_solver {
     int64_t rs_stride;            // rows + one row block
     int rs_groups;                // panel groups the scratch has room for
     int last_gridA, last_gridB;   // grids of the last primal / dual launch (adaptive reduce)
+    bool use_split;               // set by the half-step that may consume a pending local-panel product
     // optional (PDLP_GRAPH=1): pdlp_iterate replays two captured iterations (the buffer roles return after two) as one
     // hipGraph launch.  Captured on and replayed from the library's own stream (capture is not allowed on the
     // legacy null stream), ordered against the caller's stream with events.  One graph per (roles, mode).
@@ -888,22 +905,46 @@ void free_handle(pdlp_handle h)
     delete h;
 }
 
+// partial row sums of `vgroups` panel groups over `vtotal` panels in virtual order (see k_tiled_fused) into
+// rowsum[slot0 .. slot0 + vgroups); the epilogue functor is not used by these launches
+template <typename T>
+void launch_tiled_groups(pdlp_handle h, const Schedule& s, int rows, const void* vin, hipStream_t stream, int vgroups, int vtotal,
+                         int skip_lo, int skip_len, int slot0)
+{
+    const int ppg = (vtotal + vgroups - 1) / vgroups;
+    const int groups = (vtotal + ppg - 1) / ppg;          // no group without panels
+    StoreEpi<T> none{nullptr};
+    hipLaunchKernelGGL((k_tiled_fused<T, StoreEpi<T>, false>), dim3(s.t.nblk * groups), dim3(TNT), 0, stream, s.t.idx,
+                       (const T*)s.t.val, s.t.tile_ptr, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, ppg, vtotal, skip_lo,
+                       skip_len, slot0, (const T*)vin, (T*)h->rowsum, h->rs_stride, none, (double*)nullptr);
+}
+
 template <typename T, class Epi>
 int launch_csr(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* partials)
 {
+    if (!h->use_split && (h->sK.pending || h->sKT.pending)) {
+        // an early local-panel product that nobody is going to consume (the caller changed course): let it finish
+        // before the row-sum scratch is reused
+        HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_out, 0));
+        h->sK.pending = h->sKT.pending = false;
+    }
     const Schedule& s = transpose ? h->sKT : h->sK;
     if (s.nblk == 0) return PDLP_OK;
     if (s.tiled) {
         const int rows = (int)(transpose ? h->nl : h->ml);
-        const int ppg = (s.t.npanel + s.t.groups - 1) / s.t.groups;
-        if (s.t.groups == 1) {
+        if (s.t.groups == 1 && !(s.pending && h->use_split)) {
             hipLaunchKernelGGL((k_tiled_fused<T, Epi, true>), dim3(s.t.nblk), dim3(TNT), 0, h->stream, s.t.idx, (const T*)s.t.val,
-                               s.t.tile_ptr, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, ppg, (const T*)vin,
-                               (T*)h->rowsum, h->rs_stride, epi, partials);
+                               s.t.tile_ptr, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, s.t.npanel, s.t.npanel,
+                               s.t.npanel, 0, 0, (const T*)vin, (T*)h->rowsum, h->rs_stride, epi, partials);
+        } else if (s.pending && h->use_split) {
+            // the local panels were multiplied by pdlp_*_half_begin on the side stream; now the others, then the sum
+            launch_tiled_groups<T>(h, s, rows, vin, h->stream, s.slotsB, s.t.npanel - (s.loc_pb - s.loc_pa), s.loc_pa,
+                                   s.loc_pb - s.loc_pa, s.slotsA);
+            HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_out, 0));
+            hipLaunchKernelGGL((k_rowsum_epilogue<T, Epi>), dim3(grid_for(rows)), dim3(BLOCK), 0, h->stream, (const T*)h->rowsum,
+                               s.slotsA + s.slotsB, h->rs_stride, rows, epi, partials);
         } else {
-            hipLaunchKernelGGL((k_tiled_fused<T, Epi, false>), dim3(s.t.nblk * s.t.groups), dim3(TNT), 0, h->stream, s.t.idx,
-                               (const T*)s.t.val, s.t.tile_ptr, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, ppg,
-                               (const T*)vin, (T*)h->rowsum, h->rs_stride, epi, partials);
+            launch_tiled_groups<T>(h, s, rows, vin, h->stream, s.t.groups, s.t.npanel, s.t.npanel, 0, 0);
             hipLaunchKernelGGL((k_rowsum_epilogue<T, Epi>), dim3(grid_for(rows)), dim3(BLOCK), 0, h->stream, (const T*)h->rowsum,
                                s.t.groups, h->rs_stride, rows, epi, partials);
         }
@@ -926,7 +967,7 @@ inline int grid_of(const Schedule& s, int64_t rows)
 {
     if (s.nblk == 0) return 0;
     if (!s.tiled) return s.grid + (s.nlong > 0 ? s.lgrid : 0);
-    return s.t.groups == 1 ? s.t.nblk : grid_for(rows);      // split tiles: the partial sums come from k_rowsum_epilogue
+    return (s.t.groups == 1 && !s.pending) ? s.t.nblk : grid_for(rows);   // split tiles: the partial sums come from k_rowsum_epilogue
 }
 
 template <typename T> T* xloc(pdlp_handle h, int ix) { return (T*)h->xb[ix] + h->p.col0; }
@@ -939,11 +980,17 @@ template <typename T> int primal_half_t(pdlp_handle h, int adaptive)
         PrimalEpi<T, true> e{xloc<T>(h, h->ix_cur), xloc<T>(h, h->ix_prev), (T*)h->xbar + h->p.col0, (const T*)h->p.c,
                              (const T*)h->p.l, (const T*)h->p.u, (T*)h->x_sum, sc};
         h->last_gridA = grid_of(h->sKT, h->nl);
-        return launch_csr<T>(h, true, h->yb[h->ix_cur], e, h->partA);
+        h->use_split = true;
+        const int rc = launch_csr<T>(h, true, h->yb[h->ix_cur], e, h->partA);
+        h->use_split = false; h->sKT.pending = false;
+        return rc;
     }
     PrimalEpi<T, false> e{xloc<T>(h, h->ix_cur), xloc<T>(h, h->ix_prev), (T*)h->xbar + h->p.col0, (const T*)h->p.c,
                           (const T*)h->p.l, (const T*)h->p.u, (T*)h->x_sum, sc};
-    return launch_csr<T>(h, true, h->yb[h->ix_cur], e, h->partA);
+    h->use_split = true;
+    const int rc = launch_csr<T>(h, true, h->yb[h->ix_cur], e, h->partA);
+    h->use_split = false; h->sKT.pending = false;
+    return rc;
 }
 
 template <typename T> int refresh_kx_t(pdlp_handle h)
@@ -962,13 +1009,16 @@ template <typename T> int dual_half_t(pdlp_handle h, int adaptive)
         DualEpi<T, true> e{yloc<T>(h, h->ix_cur), yloc<T>(h, h->ix_prev), (const T*)h->p.q, (T*)h->y_sum, (T*)h->kxb[0],
                            h->sc, h->ineq_end};
         h->last_gridB = grid_of(h->sK, h->ml);
+        h->use_split = true;
         rc = launch_csr<T>(h, false, h->xbar, e, h->partB);
     } else {
         DualEpi<T, false> e{yloc<T>(h, h->ix_cur), yloc<T>(h, h->ix_prev), (const T*)h->p.q, (T*)h->y_sum, (T*)h->kxb[0],
                             h->sc, h->ineq_end};
+        h->use_split = true;
         rc = launch_csr<T>(h, false, h->xbar, e, h->partB);
         h->kx_valid = false;
     }
+    h->use_split = false; h->sK.pending = false;
     if (rc != PDLP_OK) return rc;
     const int t = h->ix_cur;   // the freshly written buffers become current, the old ones previous
     h->ix_cur = h->ix_prev;
@@ -1010,6 +1060,43 @@ template <typename T> void kkt_finish_t(const double* r, double omega_d, double*
     const T w = (T)omega_d, w2 = w * w;
     const T kkt = (T)std::sqrt((double)(w2 * (pr * pr) + (dr * dr) / w2 + gap * gap));
     out[0] = pr; out[1] = dr; out[2] = gap; out[3] = p; out[4] = adj; out[5] = kkt;
+}
+
+// panel groups of the split product of one matrix (see Schedule): the local panels get their share of the slots
+void configure_split(pdlp_handle h, bool transpose)
+{
+    Schedule& s = transpose ? h->sKT : h->sK;
+    s.loc_pa = s.loc_pb = s.slotsA = s.slotsB = 0;
+    s.pending = false;
+    if (!s.tiled) return;
+    const int64_t lo = transpose ? h->p.row0 : h->p.col0, hi = transpose ? h->p.row1 : h->p.col1;
+    const int64_t total = transpose ? h->p.m : h->p.n;
+    if (lo == 0 && hi == total) return;                               // not sharded: nothing to wait for
+    const int64_t W = (int64_t)1 << s.t.lw;
+    const int pa = (int)((lo + W - 1) / W), pb = hi == total ? s.t.npanel : (int)(hi / W);
+    const int nloc = pb - pa, nrem = s.t.npanel - nloc;
+    const int S = s.t.groups > 2 ? s.t.groups : 2;
+    if (nloc <= 0 || nrem <= 0 || S > h->rs_groups) return;
+    int a = (int)((double)S * nloc / s.t.npanel + 0.5);
+    a = a < 1 ? 1 : (a > S - 1 ? S - 1 : a);
+    auto norm = [](int g, int n) { g = g > n ? n : g; const int ppg = (n + g - 1) / g; return (n + ppg - 1) / ppg; };
+    s.loc_pa = pa; s.loc_pb = pb;
+    s.slotsA = norm(a, nloc);
+    s.slotsB = norm(S - a, nrem);
+}
+
+template <typename T> int half_begin_t(pdlp_handle h, bool transpose, const void* vin)
+{
+    Schedule& s = transpose ? h->sKT : h->sK;
+    if (!s.tiled || s.slotsA == 0 || !h->gstream || s.pending) return PDLP_OK;
+    const int rows = (int)(transpose ? h->nl : h->ml);
+    HIP_TRY(hipEventRecord(h->ev_in, h->stream));
+    HIP_TRY(hipStreamWaitEvent(h->gstream, h->ev_in, 0));
+    launch_tiled_groups<T>(h, s, rows, vin, h->gstream, s.slotsA, s.loc_pb - s.loc_pa, 0, s.loc_pa, 0);
+    HIP_TRY(hipEventRecord(h->ev_out, h->gstream));
+    HIP_TRY(hipGetLastError());
+    s.pending = true;
+    return PDLP_OK;
 }
 
 #define DISPATCH(h, fn, ...) ((h)->p.dtype == PDLP_F32 ? fn<float>(__VA_ARGS__) : fn<double>(__VA_ARGS__))
@@ -1218,10 +1305,16 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     // opt-in (PDLP_GRAPH=1): on ROCm 7.2 / MI355X the replay measured 6-12 % SLOWER than direct launches on the small
     // LPs it was meant for (neos3-shaped: 17.8k vs 20.2k it/s; 1M x 1M, 5 nnz/row: 10.25k vs 10.86k it/s) -- the loop is
     // bound by dependent-kernel latency on the device, not by host launch cost -- and makes no difference on large ones
-    h->graph_ok = std::getenv("PDLP_GRAPH") != nullptr &&
-                  hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking) == hipSuccess &&
-                  hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) == hipSuccess &&
-                  hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) == hipSuccess;
+    const bool side = hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking) == hipSuccess &&
+                      hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) == hipSuccess &&
+                      hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) == hipSuccess;
+    if (!side) {                  // no side stream: no graph replay and no early local-panel products
+        if (h->gstream) (void)hipStreamDestroy(h->gstream);
+        h->gstream = nullptr;
+        (void)hipGetLastError();
+    }
+    h->graph_ok = side && std::getenv("PDLP_GRAPH") != nullptr;
+    h->use_split = false;
 
     std::vector<int32_t> sched;
     build_schedule_host(rpK, ml, sched);
@@ -1292,7 +1385,7 @@ int pdlp_attach_tiles(pdlp_handle h, int transpose, const pdlp_tiles* t)
     if (!h) return PDLP_ERR_INVALID;
     Schedule& s = transpose ? h->sKT : h->sK;
     drop_graphs(h);               // captured launches name the old kernel and arrays
-    if (!t) { s.tiled = false; return PDLP_OK; }
+    if (!t) { s.tiled = false; configure_split(h, transpose != 0); return PDLP_OK; }
     const int64_t rows = transpose ? h->nl : h->ml;
     const int rpt_max = h->p.dtype == PDLP_F32 ? TileCfg<float>::RPT_MAX : TileCfg<double>::RPT_MAX;
     const int cap_max = h->p.dtype == PDLP_F32 ? TileCfg<float>::CAP : TileCfg<double>::CAP;
@@ -1306,6 +1399,7 @@ int pdlp_attach_tiles(pdlp_handle h, int transpose, const pdlp_tiles* t)
     if (((uintptr_t)t->idx & 15u) || ((uintptr_t)t->val & 15u) || ((uintptr_t)t->cnt & 3u)) return PDLP_ERR_INVALID;
     s.t = *t;
     s.tiled = true;
+    configure_split(h, transpose != 0);
     return PDLP_OK;
 }
 
@@ -1373,6 +1467,27 @@ int pdlp_dual_half(pdlp_handle h, int adaptive)
 {
     if (!h) return PDLP_ERR_INVALID;
     return DISPATCH(h, dual_half_t, h, adaptive);
+}
+
+int pdlp_primal_half_begin(pdlp_handle h)
+{
+    if (!h) return PDLP_ERR_INVALID;
+    return DISPATCH(h, half_begin_t, h, true, h->yb[h->ix_cur]);
+}
+
+int pdlp_dual_half_begin(pdlp_handle h, int adaptive)
+{
+    if (!h) return PDLP_ERR_INVALID;
+    if (adaptive && !h->kx_valid) return PDLP_OK;        // the K x refresh ahead of this half-step uses the same scratch
+    return DISPATCH(h, half_begin_t, h, false, h->xbar);
+}
+
+int pdlp_split_info(pdlp_handle h, int transpose, int32_t out[4])
+{
+    if (!h || !out) return PDLP_ERR_INVALID;
+    const Schedule& s = transpose ? h->sKT : h->sK;
+    out[0] = s.loc_pa; out[1] = s.loc_pb; out[2] = s.slotsA; out[3] = s.slotsB;
+    return PDLP_OK;
 }
 
 int pdlp_adaptive_reduce(pdlp_handle h)

@@ -146,6 +146,12 @@ class PdlpEngine:
         N.check(self.lib.pdlp_attach_tiles(self.h, int(transpose), C.byref(desc)), "pdlp_attach_tiles")
         self.tiles[int(transpose)] = t       # keep the arrays alive
 
+    def split_info(self, transpose: int) -> dict:
+        """how a sharded product is split so that its local panels overlap the all-gather (zeros: not split)"""
+        out = (C.c_int32 * 4)()
+        N.check(self.lib.pdlp_split_info(self.h, int(transpose), out), "pdlp_split_info")
+        return dict(local_panels=(out[0], out[1]), local_groups=out[2], other_groups=out[3])
+
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
         if h:
@@ -216,10 +222,16 @@ class PdlpEngine:
         a = int(adaptive)
         lib, h, comm = self.lib, self.h, self.comm
         xbar, red = self.buffer(N.BUF_XBAR), self.buffer(N.BUF_RED)      # fixed addresses
-        for _ in range(int(iters)):
+        iters = int(iters)
+        for it in range(iters):
             N.check(lib.pdlp_primal_half(h, a), "pdlp_primal_half")
+            # the panels of K that meet this rank's own block of xbar are multiplied (side stream) while the
+            # other blocks are still on the wire; the same for K' and y below
+            N.check(lib.pdlp_dual_half_begin(h, a), "pdlp_dual_half_begin")
             comm.all_gather(xbar)                          # K xbar needs every rank's block of xbar
             N.check(lib.pdlp_dual_half(h, a), "pdlp_dual_half")
+            if it + 1 < iters:                             # (the new y is final: a rejected adaptive step is kept, quirk Q1)
+                N.check(lib.pdlp_primal_half_begin(h), "pdlp_primal_half_begin")
             comm.all_gather(self.buffer(N.BUF_Y_CUR))      # the next K'y needs every rank's block of y (buffers alternate)
             if adaptive:
                 N.check(lib.pdlp_adaptive_reduce(h), "pdlp_adaptive_reduce")
