@@ -3,8 +3,8 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/_bin
-for v in FULL NOPASS2 NOGATHER NOLDSW; do
-  flags=""; [ "$v" != FULL ] && flags="-DPDLP_ABL_$v"
+for v in FULL NOGATHER STAMPS; do
+  flags=""; [ "$v" = NOGATHER ] && flags="-DPDLP_ABL_NOGATHER"; [ "$v" = STAMPS ] && flags="-DPDLP_STAMPS"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Iinclude $flags \
      torchpdlp_amd/csrc/pdlp_hip.hip -o tools/_bin/libpdlp_$v.so 2>/dev/null &
 done

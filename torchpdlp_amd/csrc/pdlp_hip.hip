@@ -444,7 +444,6 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
         // unconditionally and selected by the row's count (no load-to-use chains, no exec masking; reading past
         // a short row touches the next rows' items or the 8-word tail of the buffer); longer segments (0.06 % of
         // the (row, tile) pairs at 0.65 items per pair) finish in a loop.
-#ifndef PDLP_ABL_NOPASS2
 #pragma unroll
         for (int q = 0; q < TCW; ++q) {
             if (8 * q < rpt) {
@@ -485,9 +484,6 @@ __global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restri
                 }
             }
         }
-#else
-        acc[1] += (T)(sbase + cw[0]);
-#endif
         STAMP(st_p2);
         __syncthreads();
         STAMP(st_s2);
