@@ -155,6 +155,13 @@ def _gpu_worker(rank, world, port, ret):
                 np.testing.assert_allclose(trace["kkt"][:nk], tr1["kkt"][:nk], rtol=5e-2 if adaptive else 1e-3)
                 assert trace["restarts"][:1] == tr1["restarts"][:1]
                 assert j == k + (len(trace["kkt"]) - n) + 2 * n
+        # the user-facing entry point, sharded: every rank passes the whole problem and gets the whole solution
+        res = tp.solve_lp((lp.c, K, lp.q, lp.m_ineq, lp.l, lp.u), device=dev, tol=1e-4, precondition=True,
+                          primal_weight_update=True, adaptive_stepsize=True, seed=1, comm=True)
+        assert res.status == "Solved" and res.x.shape == (lp.n, 1)
+        assert abs(res.objective - lp.opt_obj) <= 2e-3 * (1 + abs(lp.opt_obj))
+        xs = res.x.view(-1)
+        assert float((lp.c.view(-1).to(xs) * xs).sum()) == pytest.approx(res.objective, rel=1e-3, abs=1e-3)
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()

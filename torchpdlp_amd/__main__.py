@@ -52,7 +52,18 @@ def main(argv=None) -> int:
     if args.device == "cpu" or not torch.cuda.is_available():
         print("torchpdlp_amd needs a HIP device: there is no CPU solver path in this package.", file=sys.stderr)
         return 2
-    print(f"PyTorch is using ROCm/CUDA device: {torch.cuda.get_device_name(0)}")
+    # under torchrun (one process per GPU) every instance is sharded over the ranks; rank 0 reports
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        if not dist.is_initialized():
+            dist.init_process_group(os.environ.get("PDLP_DIST_BACKEND", "nccl"))
+        comm = True
+    if rank == 0:
+        print(f"PyTorch is using ROCm/CUDA device: {torch.cuda.get_device_name(torch.cuda.current_device())}"
+              + (f" x {world} ranks" if world > 1 else ""))
     files = sorted(f for f in os.listdir(args.instance_path) if f.endswith(".mps"))       # main.py:83
     results = []
     for name in files:
@@ -64,13 +75,15 @@ def main(argv=None) -> int:
             r = solve_lp(path, tol=args.tolerance, precondition=args.precondition, primal_weight_update=args.primal_weight_update,
                          adaptive_stepsize=args.adaptive_stepsize, max_kkt=args.max_kkt, time_limit=args.time_limit,
                          verbose=args.verbose, dtype=torch.float32 if args.dtype == "fp32" else torch.float64, seed=args.seed,
-                         compat=not args.standard_mps, fishnet=args.fishnet)
+                         compat=not args.standard_mps, fishnet=args.fishnet, comm=comm)
             print(f"Solver uses {r.time:.4f} seconds.\nStatus: {r.status}")
             results.append({"File": name, "Objective": f"{r.objective:.6f}", "Iterations (k)": r.iterations, "Restarts (n)": r.restarts,
                             "KKT Passes (j)": r.kkt_passes, "Time (s)": f"{r.time:.4f}", "Status": r.status})      # main.py:142-150
         except Exception as e:          # the reference records the failure and goes on (main.py:152-162)
             print(f"Solver failed for {name}. Error: {e}")
             results.append(_fail_row(name, "Solver failed", e))
+    if rank != 0:
+        return 0
     os.makedirs(args.output_path, exist_ok=True)
     if results:
         out = os.path.join(args.output_path, "solver_results.csv")

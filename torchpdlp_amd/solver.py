@@ -202,7 +202,12 @@ def run_pdlp(eng: PdlpEngine, max_kkt=100_000, tol=1e-4, verbose=True, restart_p
     while drv.j < max_kkt:                                                  # pdhg.py:54
         n_before = drv.n
         while drv.j < max_kkt and drv.n == n_before:                        # pdhg.py:67
-            if time.time() - t0 + time_used >= time_limit:                  # pdhg.py:68-74 (checked per block)
+            expired = time.time() - t0 + time_used >= time_limit            # pdhg.py:68-74 (checked per block)
+            if eng.comm is not None:                                        # every rank must leave together: rank 0's clock decides
+                flag = torch.tensor([int(expired)], dtype=torch.int32, device=eng.device)
+                eng.comm.dist.broadcast(flag, 0, group=eng.comm.group)
+                expired = bool(int(flag.cpu()))
+            if expired:
                 status = STATUS_TIME_LIMIT
                 if verbose:
                     print("Time limit exceeded")
@@ -226,7 +231,7 @@ def run_pdlp(eng: PdlpEngine, max_kkt=100_000, tol=1e-4, verbose=True, restart_p
 def pdlp_algorithm(K, m_ineq, c, q, l, u, device=None, max_kkt=100_000, tol=1e-4, verbose=True, restart_period=40,
                    precondition=False, primal_update=False, adaptive=False, data_precond=None, infeasibility_detect=False,
                    infeas_tol=1e-4, time_limit=3600, time_used=0, x_init=None, y_init=None, *, b0=None, sigma=None,
-                   seed=None, trace=None):
+                   seed=None, trace=None, comm=None):
     """Drop-in for the reference's ``pdlp_algorithm`` (primal_dual_hybrid_gradient.py:7) on one MI355X.
 
     ``K`` may be a dense / COO torch tensor (as the reference takes), a scipy sparse matrix or a
@@ -235,6 +240,10 @@ def pdlp_algorithm(K, m_ineq, c, q, l, u, device=None, max_kkt=100_000, tol=1e-4
     ``seed`` pin the power-iteration start the reference leaves to an unseeded RNG.
     Returns ``(x, prim_obj, k, n, j, status, total_time)``; ``x`` is an (n,1) tensor and, like the
     reference's (quirk Q4), the SCALED iterate when preconditioned.
+
+    ``comm`` (a ``Comm``, or ``True`` for the default ``torch.distributed`` group): every rank calls with the SAME
+    full problem and the same ``seed``/``b0``; each keeps its row blocks of K and K', the iterations exchange
+    ``xbar`` and ``y`` over RCCL, and every rank returns the full solution.
     """
     if infeasibility_detect:
         raise NotImplementedError("infeasibility detection is outside the accelerated hot path (SURVEY.md 8f row f4)")
@@ -248,6 +257,28 @@ def pdlp_algorithm(K, m_ineq, c, q, l, u, device=None, max_kkt=100_000, tol=1e-4
         if data_precond is None:
             raise ValueError("precondition=True needs data_precond from ruiz_precondition")
         d_col, d_row = data_precond[0], data_precond[1]
+    if comm is True:
+        comm = Comm()
+    if comm is not None and comm.world > 1:
+        from .distributed import gather_solution, shard_engine
+        if seed is None and b0 is None and sigma is None:
+            seed = 0                                   # the ranks must draw the same power-iteration start
+        eng = shard_engine(Kp, c, q, l, u, m_ineq, comm, d_col=d_col, d_row=d_row)
+        if x_init is not None and y_init is not None:  # full vectors in, this rank's (zero padded) blocks on
+            xi = torch.zeros(eng.n, dtype=dtype, device=device)
+            yi = torch.zeros(eng.m, dtype=dtype, device=device)
+            xi[:Kp.n] = as_vec(x_init, Kp.n, device, dtype)
+            yi[:Kp.m] = as_vec(y_init, Kp.m, device, dtype)
+            x_init, y_init = xi[eng.cols[0]:eng.cols[1]], yi[eng.rows[0]:eng.rows[1]]
+        if b0 is not None:
+            bp = torch.zeros(eng.n, dtype=torch.float32, device=device)
+            bp[:Kp.n] = as_vec(b0, Kp.n, device, torch.float32)
+            b0 = bp
+        verbose = verbose and comm.rank == 0
+        x, obj, k, n, j, status, total = run_pdlp(eng, max_kkt, tol, verbose, restart_period, precondition, primal_update,
+                                                  adaptive, time_limit, time_used, x_init, y_init, b0=b0, sigma=sigma,
+                                                  seed=seed, trace=trace)
+        return gather_solution(eng, x, Kp.n).view(-1, 1), obj, k, n, j, status, total
     eng = PdlpEngine.from_full(Kp, c, q, l, u, m_ineq, d_col=d_col, d_row=d_row)
     x, obj, k, n, j, status, total = run_pdlp(eng, max_kkt, tol, verbose, restart_period, precondition, primal_update, adaptive,
                                               time_limit, time_used, x_init, y_init, b0=b0, sigma=sigma, seed=seed, trace=trace)
