@@ -17,6 +17,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -1071,10 +1072,26 @@ void configure_split(pdlp_handle h, bool transpose)
     const int64_t W = (int64_t)1 << s.t.lw;
     const int pa = (int)((lo + W - 1) / W), pb = hi == total ? s.t.npanel : (int)(hi / W);
     const int nloc = pb - pa, nrem = s.t.npanel - nloc;
-    const int S = s.t.groups > 2 ? s.t.groups : 2;
-    if (nloc <= 0 || nrem <= 0 || S > h->rs_groups) return;
-    int a = (int)((double)S * nloc / s.t.npanel + 0.5);
-    a = a < 1 ? 1 : (a > S - 1 ? S - 1 : a);
+    if (nloc <= 0 || nrem <= 0 || h->rs_groups < 2) return;
+    // Measured on shard-shaped matrices with a spin kernel standing in for the gather (tools/split_timing.py):
+    // each launch must fit ONE round of workgroups (2 per CU) or its tail costs more than the overlap gains; the
+    // other panels take as many groups as fit; the local panels enough groups that a workgroup walks <= ~13 panels
+    // and is done by the time the gather is.  10M x 10M: 8 ranks (2 + 8 groups) 0.402 -> 0.380 ms per half-step,
+    // 4 ranks (3 + 4) 0.677 -> 0.573 ms, 2 ranks (2 + 2) 1.27 -> 1.01 ms.
+    const int round_slots = 2 * 256;
+    int fit = round_slots / (s.t.nblk > 0 ? s.t.nblk : 1);
+    fit = fit < 1 ? 1 : fit;
+    int b = fit < nrem ? fit : nrem;
+    int a = (nloc + 12) / 13;
+    a = a > fit ? fit : a;
+    a = a > nloc ? nloc : a;
+    if (a + b > h->rs_groups) b = h->rs_groups - a;
+    if (a < 1 || b < 1) return;
+    int S = a + b;
+    if (const char* ov = std::getenv("PDLP_SPLIT_SLOTS")) {           // experiments: "local,other"
+        int oa = 0, ob = 0;
+        if (std::sscanf(ov, "%d,%d", &oa, &ob) == 2 && oa >= 1 && ob >= 1 && oa + ob <= h->rs_groups) { a = oa; S = oa + ob; }
+    }
     auto norm = [](int g, int n) { g = g > n ? n : g; const int ppg = (n + g - 1) / g; return (n + ppg - 1) / ppg; };
     s.loc_pa = pa; s.loc_pb = pb;
     s.slotsA = norm(a, nloc);
@@ -1176,7 +1193,11 @@ int check_problem(const pdlp_problem* p)
 
 // panel groups the row-sum scratch is sized for: splitting only pays when one workgroup per (largest) row block
 // cannot fill 2 x 256 CUs, i.e. below about 10.5M rows
-inline int64_t rowsum_groups(int64_t rows) { return rows <= (int64_t)TNT * TRPT_MAX_ANY * 512 ? 8 : 1; }
+inline int64_t rowsum_groups(int64_t rows)
+{
+    if (rows <= (int64_t)TNT * TRPT_MAX_ANY * 128) return 16;     // (small shards: room to split local / other panels finely)
+    return rows <= (int64_t)TNT * TRPT_MAX_ANY * 512 ? 8 : 1;
+}
 
 struct Carve {
     int64_t off = 0;
