@@ -98,3 +98,17 @@ def test_choose_rpt_fills_whole_rounds():
     rpt8, g8 = choose_shape(1_250_000, 125_000_000, 10_000_000, 16)
     assert rpt8 >= 32 and g8 == 8 and 0.9 < -(-1_250_000 // (512 * rpt8)) * g8 / 512 <= 1.0
     assert choose_shape(100, 300, 50, 16) == (choose_rpt(100, 300, 50, 16), 1)          # a single panel cannot be split
+
+
+def test_panel_width_adapts_to_long_rows():
+    from torchpdlp_amd.tiled import choose_lw
+    assert choose_lw(10_000_000, 1_000_000_000, 10_000_000) == 16            # the bench matrix: 0.66 items per (row, panel)
+    assert choose_lw(1_000_000, 100_000_000, 1_000_000) == 14                # 100 per row over 1M columns: 6.6 at 64K, 1.6 at 16K
+    m, n = 2000, 70_000
+    rp, ci, va = _csr(m, n, np.full(m, 20), 11)
+    assert build_tiles(rp, ci, va, m, n, lw=16) is None                      # 64 rows x 18.7 items per panel > 255
+    t = build_tiles(rp, ci, va, m, n)                                        # auto: 8K-column panels
+    assert t is not None and t.lw == 13
+    x = torch.from_numpy(np.random.default_rng(1).standard_normal(n).astype(np.float32))
+    ref = sp.csr_matrix((va.numpy().astype(np.float64), ci.numpy(), rp.numpy()), shape=(m, n)) @ x.numpy().astype(np.float64)
+    np.testing.assert_allclose(emulate_spmv(t, x).numpy(), ref, rtol=1e-12, atol=1e-12)

@@ -115,6 +115,17 @@ def choose_shape(nrows: int, nnz: int, ncols: int, lw: int, cap: int = CAP, slot
     return best
 
 
+def choose_lw(nrows: int, nnz: int, ncols: int) -> int:
+    """log2 of the panel width: 64K columns unless the rows are so long that 64 consecutive rows would hold more
+    than the 255 items of a tile the kernel's 8-bit scan fields allow -- then narrower panels (down to 4K)"""
+    per_row = nnz / max(nrows, 1)
+    for lw in range(LW_DEFAULT, 11, -1):
+        W = 1 << lw
+        if per_row * min(W, ncols) / max(ncols, 1) <= 3.0:          # mean 192 per 64 rows: 4.5 sigma below 255
+            return lw
+    return 12
+
+
 def normalize_groups(groups: int, npanel: int, max_groups: int = 8) -> int:
     """the kernel gives every group ceil(npanel/groups) panels: shrink the count until no group is empty"""
     g = max(1, min(int(groups), npanel, max_groups))
@@ -127,7 +138,7 @@ def choose_rpt(nrows: int, nnz: int, ncols: int, lw: int, cap: int = CAP, ncu: i
 
 
 def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, nrows: int, ncols: int,
-                lw: int = LW_DEFAULT, rpt: Optional[int] = None, cap: Optional[int] = None, max_chunk_nnz: int = 1 << 26,
+                lw: Optional[int] = None, rpt: Optional[int] = None, cap: Optional[int] = None, max_chunk_nnz: int = 1 << 26,
                 groups: Optional[int] = None) -> Optional[Tiles]:
     """CSR (any row lengths, columns sorted or not) -> Tiles, or None when not eligible.  Runs on the
     tensors' device with torch sorts (setup cost, done once per matrix)."""
@@ -138,6 +149,8 @@ def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, n
     cap = cap_max if cap is None else cap
     CW = rpt_max // 8
     nnz = int(colidx.numel())
+    if lw is None:
+        lw = choose_lw(nrows, nnz, ncols)
     W = 1 << lw
     if rpt is None:
         rpt, g_auto = choose_shape(nrows, nnz, ncols, lw, cap, rpt_max=rpt_max)
