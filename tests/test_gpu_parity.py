@@ -703,3 +703,47 @@ def test_graph_replay_is_bitwise_the_direct_launch_loop(monkeypatch):
         np.testing.assert_array_equal(a[0], b[0])
         np.testing.assert_array_equal(a[1], b[1])
         assert a[2:] == b[2:]
+
+
+def test_tiled_kernel_random_shapes_match_csr():
+    """a sweep over panel widths, rows per thread, panel groups and row-length laws (incl. counts of 15 per (row, tile),
+    wave totals close to the 255 the scan fields hold, empty tiles, odd rpt, ragged last block): tiled vs CSR kernel"""
+    from torchpdlp_amd.tiled import build_tiles
+    rng = np.random.default_rng(77)
+    tried = 0
+    for case in range(24):
+        m = int(rng.integers(600, 60_000))
+        n = int(rng.integers(3_000, 400_000))
+        lw = int(rng.integers(8, 17))
+        law = case % 4
+        if law == 0:
+            lens = rng.integers(0, 9, m)
+        elif law == 1:                                        # few heavy rows among empty ones
+            lens = np.where(rng.random(m) < 0.05, rng.integers(20, 60, m), 0)
+        elif law == 2:                                        # ~3.5 per (row, panel): wave totals around 225
+            npanel = -(-n // (1 << lw))
+            lens = np.full(m, min(int(3.5 * npanel), n // 2, 400))
+        else:
+            lens = (rng.pareto(1.2, m) * 3).astype(np.int64).clip(0, 80)
+        rp, ci, va = _random_csr(m, n, lens, 100 + case)
+        K = tp.CsrPair(m, n, dev(rp, torch.int32), dev(ci, torch.int32), dev(va))
+        z = lambda k: torch.zeros(k, device=DEV)
+        eng = tp.PdlpEngine.from_full(K, z(n), z(m), z(n), z(n), 0)
+        eng.attach_tiles(0, None)
+        eng.attach_tiles(1, None)
+        x = dev(rng.standard_normal(n).astype(np.float32))
+        ref = eng.spmv(x, False).cpu().numpy()
+        rpt = int(rng.integers(1, 41)) if case % 3 else None
+        groups = int(rng.integers(1, 9))
+        try:
+            t = build_tiles(eng.K[0], eng.K[1], eng.K[2], m, n, lw=lw, rpt=rpt, groups=groups)
+        except ValueError:
+            t = None
+        if t is None:
+            continue
+        tried += 1
+        eng.attach_tiles(0, t)
+        got = eng.spmv(x, False).cpu().numpy()
+        scale = np.abs(ref).max() + 1.0
+        np.testing.assert_allclose(got / scale, ref / scale, rtol=0, atol=3e-6, err_msg=f"case {case}: m={m} n={n} lw={lw} rpt={t.rpt} groups={t.groups}")
+    assert tried >= 12
