@@ -113,7 +113,9 @@ class PdlpEngine:
         for transpose, (rp, ci, va), rows, cols in ((0, self.K, self.ml, self.n), (1, self.KT, self.nl, self.m)):
             if rows == 0 or (mode != "1" and (cols < (1 << 16) or int(va.numel()) < (1 << 20))):
                 continue
-            t = _tiled.build_tiles(rp, ci, va, rows, cols)
+            knob = lambda name: int(os.environ[name]) if os.environ.get(name) else None      # tuning experiments
+            t = _tiled.build_tiles(rp, ci, va, rows, cols, lw=knob("PDLP_TILE_LW"), rpt=knob("PDLP_TILE_RPT"),
+                                   groups=knob("PDLP_TILE_GROUPS"))
             if t is None:
                 continue
             if mode == "1":
