@@ -35,6 +35,27 @@ __global__ __launch_bounds__(256) void k_gather(const int* __restrict__ idx, con
     if (s == 123.456f) out[0] = s;
 }
 
+// the same gathers issued as buffer loads (SGPR resource descriptor + 32-bit VGPR byte offset) instead of flat global loads
+__global__ __launch_bounds__(256) void k_gather_buf(const int* __restrict__ idx, const float* __restrict__ val,
+                                                    const float* __restrict__ table, unsigned table_bytes, size_t n, float* out)
+{
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)table, 0, (int)table_bytes, 0x00020000);
+    float s = 0;
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const int i0 = idx[i], i1 = idx[i + stride], i2 = idx[i + 2 * stride], i3 = idx[i + 3 * stride];
+        const float v0 = val[i], v1 = val[i + stride], v2 = val[i + 2 * stride], v3 = val[i + 3 * stride];
+        const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, i0 * 4, 0, 0));
+        const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, i1 * 4, 0, 0));
+        const float t2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, i2 * 4, 0, 0));
+        const float t3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, i3 * 4, 0, 0));
+        s += v0 * t0 + v1 * t1 + v2 * t2 + v3 * t3;
+    }
+    for (; i < n; i += stride) s += val[i] * table[idx[i]];
+    if (s == 123.456f) out[0] = s;
+}
+
 // table window copied to LDS first (window = wsize floats), each block loops over its share of the index stream
 __global__ __launch_bounds__(256) void k_gather_lds(const int* __restrict__ idx, const float* __restrict__ val,
                                                     const float* __restrict__ table, int wsize, size_t n, float* out)
@@ -140,6 +161,19 @@ int main(int argc, char** argv)
         fill(tsize, 1);
         snprintf(name, sizeof name, "gather table %6zu KiB random", tsize * 4 >> 10);
         run(name, n, 8, [&] { hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), 0, 0, d_idx, d_val, d_table, n, d_out); });
+    }
+    // buffer loads vs flat global loads for the same gathers
+    for (size_t tsize : {(size_t)64 << 10, (size_t)1 << 20}) {
+        fill(tsize, 1);
+        snprintf(name, sizeof name, "gather table %6zu KiB random, global", tsize * 4 >> 10);
+        run(name, n, 8, [&] { hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), 0, 0, d_idx, d_val, d_table, n, d_out); });
+        snprintf(name, sizeof name, "gather table %6zu KiB random, buffer", tsize * 4 >> 10);
+        run(name, n, 8, [&] { hipLaunchKernelGGL(k_gather_buf, dim3(grid), dim3(256), 0, 0, d_idx, d_val, d_table, (unsigned)(tsize * 4), n, d_out); });
+    }
+    {
+        fill((size_t)64 << 10, 32768);
+        run("gather 256 KiB, sorted windows 32768, global", n, 8, [&] { hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), 0, 0, d_idx, d_val, d_table, n, d_out); });
+        run("gather 256 KiB, sorted windows 32768, buffer", n, 8, [&] { hipLaunchKernelGGL(k_gather_buf, dim3(grid), dim3(256), 0, 0, d_idx, d_val, d_table, (unsigned)((64 << 10) * 4), n, d_out); });
     }
     // line sharing: consecutive items sorted inside windows (the wave's 64 lanes then touch few lines)
     if (!quick)
