@@ -57,7 +57,8 @@ def main(argv=None) -> int:
     comm = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        # (PDLP_SHARE_GPU=1 + PDLP_DIST_BACKEND=gloo: rehearsal of the sharded path on a one-GPU box)
+        torch.cuda.set_device(0 if os.environ.get("PDLP_SHARE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0")))
         if not dist.is_initialized():
             dist.init_process_group(os.environ.get("PDLP_DIST_BACKEND", "nccl"))
         comm = True
