@@ -46,7 +46,9 @@ enum {
     PDLP_BUF_Y_CUR = 4, PDLP_BUF_Y_PREV = 5, PDLP_BUF_Y_AVG = 6,                       /* full length m */
     PDLP_BUF_RED = 7,        /* double[PDLP_NRED]: partial sums awaiting a cross-rank all-reduce          */
     PDLP_BUF_X_SUM = 8, PDLP_BUF_Y_SUM = 9,   /* local length: eta-weighted sums (pdhg.py:107-108)         */
-    PDLP_BUF_SCALARS = 10    /* double[PDLP_NSCAL]: eta, omega, theta, tau, sigma, w_pending, eta_sum, k  */
+    PDLP_BUF_SCALARS = 10,   /* double[PDLP_NSCAL]: eta, omega, theta, tau, sigma, w_pending, eta_sum, k  */
+    PDLP_BUF_DX = 11,        /* full length n: x - x_prev of the last step (infeasibility detection)      */
+    PDLP_BUF_DY = 12         /* full length m: y - y_prev                                                 */
 };
 #define PDLP_NRED 8
 #define PDLP_NSCAL 16
@@ -187,6 +189,26 @@ int pdlp_restart_distance_local(pdlp_handle h);
 /* x_last_restart, y_last_restart <- current iterate -- pdhg.py:63-64 */
 int pdlp_mark_restart_point(pdlp_handle h);
 int pdlp_read_red(pdlp_handle h, double out[PDLP_NRED]);   /* synchronises the stream */
+
+/* ---- infeasibility detection (opt-in) ------------------------------------------------------- */
+/* Replaces detect_infeasibility (enhancements.py:80-161) and the lambda bookkeeping around it
+ * (primal_dual_hybrid_gradient.py:39-40,89-101) for the step just taken (PDLP_CUR against PDLP_PREV).
+ * Call order per iteration: pdlp_infeas_begin -> [all-gather PDLP_BUF_DX, PDLP_BUF_DY when sharded] ->
+ * pdlp_infeas_local -> [all-reduce PDLP_BUF_RED] -> pdlp_infeas_finish.
+ * pdlp_infeas_reset: lam_prev = 0 (pdhg.py:39-40); a new handle starts that way. */
+int pdlp_infeas_reset(pdlp_handle h);
+/* this rank's blocks of dx = x - x_prev (enhancements.py:108) and dy = y - y_prev (:109) into PDLP_BUF_DX / PDLP_BUF_DY */
+int pdlp_infeas_begin(pdlp_handle h);
+/* K'dy, then lam = project_lambda_box(c - K'y) (pdhg.py:90) with dlam, the dual residual K'dy - dlam (:146), the
+ * bound products (:150-157), c'dx (:124) and the per-variable bound test (:128-139) fused into the product's epilogue,
+ * then K dx with the equality norm (:118), the inequality test (:121), dy_in >= -tol (:148) and q'dy (:149) fused.
+ * Needs y, PDLP_BUF_DX and PDLP_BUF_DY complete.  Sums of this rank's block -> PDLP_BUF_RED[0..7]; lam_prev <- lam. */
+int pdlp_infeas_local(pdlp_handle h, double tol);
+/* reads PDLP_BUF_RED (after the caller's all-reduce) and decides as enhancements.py:118-142 / :148-159:
+ * *status = 0 (None), 1 ("DUAL_INFEASIBLE"), 2 ("PRIMAL_INFEASIBLE");
+ * diag = { ||K_eq dx||, #{K_in dx < -tol}, c'dx, #{bound test fails}, ||K'dy - dlam||, #{dy_in < -tol}, q'dy,
+ *          l_f'dlam_minus + u_f'dlam_plus }.  Synchronises the stream. */
+int pdlp_infeas_finish(pdlp_handle h, double tol, int32_t* status, double diag[8]);
 
 /* ---- plain products (power iteration helpers.py:41-51, tests) ------------------------------- */
 /* out_local = K in_full (transpose=0, out has row1-row0 values) or K' in_full (transpose=1) */

@@ -18,6 +18,7 @@ Groups:
   G7 power_iter.npz      spectral_norm_estimate_torch     (helpers.py:41-51)
   G8 mps.npz             mps_to_standard_form on tests/golden/mps/*.mps (util.py:76-268)
   G9 afiro.npz           Netlib afiro: util.mps_to_standard_form + pdlp_algorithm (+ ruiz_precondition)
+  G10 infeasibility.npz  detect_infeasibility (enhancements.py:80-161) and pdlp_algorithm(infeasibility_detect=True)
 """
 import contextlib
 import io
@@ -345,8 +346,80 @@ def g9_afiro():
     np.savez_compressed(os.path.join(HERE, "afiro.npz"), **out)
 
 
+def tiny_infeas_lps():
+    """name -> (K dense, m_ineq, c, q, l, u): hand-made LPs for the detector's branches."""
+    inf = float("inf")
+    T = lambda *v: torch.tensor(v, dtype=torch.float32)
+    lps = {}
+    # primal infeasible: x1 + x2 >= 3 with x in [0,1]^2 ... and an equality that is fine
+    lps["primal_infeasible_box"] = (torch.tensor([[1.0, 1.0], [1.0, -1.0]]), 1, T(1.0, 1.0), T(3.0, 0.0), T(0.0, 0.0), T(1.0, 1.0))
+    # primal infeasible with one-sided bounds: -x1 - x2 >= 1, x >= 0
+    lps["primal_infeasible_cone"] = (torch.tensor([[-1.0, -1.0]]), 1, T(1.0, 2.0), T(1.0), T(0.0, 0.0), T(inf, inf))
+    # unbounded: min -x1 - x2, x1 - x2 = 0, x >= 0
+    lps["unbounded_ray"] = (torch.tensor([[1.0, -1.0]]), 0, T(-1.0, -1.0), T(0.0), T(0.0, 0.0), T(inf, inf))
+    # unbounded below through a variable without lower bound: min x1, x1 + x2 >= 1, x1 <= 5 (l = -inf), x2 in [0,1]
+    lps["unbounded_free_below"] = (torch.tensor([[1.0, 1.0]]), 1, T(1.0, 0.0), T(1.0), T(-inf, 0.0), T(5.0, 1.0))
+    # feasible and bounded, every variable boxed: the detector fires once the iterates stall
+    lps["feasible_boxed"] = (torch.tensor([[1.0, 2.0, 0.5], [1.0, -1.0, 1.0]]), 1, T(1.0, -1.0, 0.5), T(1.0, 0.25),
+                             T(0.0, 0.0, -1.0), T(2.0, 1.5, 1.0))
+    # feasible and bounded, c < 0 on a variable with u = +inf: no branch of the bound test holds for it
+    lps["feasible_mixed"] = (torch.tensor([[1.0, 1.0, 1.0], [1.0, -1.0, 0.0]]), 1, T(-1.0, 1.0, 2.0), T(-4.0, 0.0),
+                             T(0.0, 0.0, 0.0), T(inf, inf, 3.0))
+    lps["feasible_mixed"] = (torch.tensor([[-1.0, -1.0, -1.0], [1.0, -1.0, 0.0]]), 1, T(-1.0, 1.0, 2.0), T(-4.0, 0.0),
+                             T(0.0, 0.0, 0.0), T(inf, inf, 3.0))
+    return lps
+
+
+def g10_infeasibility(cases):
+    out = {}
+    # (a) the operator on consecutive PDHG iterates of the seeded LPs, over a ladder of tolerances so that every
+    #     threshold test of the detector flips somewhere along it
+    tols = [1e-6, 1e-4, 1e-3, 1e-2, 3e-2, 1e-1, 3e-1, 1.0, 3.0, 10.0, 1e2, 1e3, 1e5]
+    for name, lp in cases.items():
+        K, x, y, eta, omega = start_state(lp, 400)
+        put(out, f"op/{name}", lp_arrays(lp))
+        inn, ipn, _, _ = masks(lp.l, lp.u)
+        c, q, l, u = col(lp.c), col(lp.q), col(lp.l), col(lp.u)
+        xs, ys = [col(x)], [col(y)]
+        for it in range(3):
+            xn, yn, _, _ = ref_step.fixed_one_step_pdhg(xs[-1].clone(), ys[-1].clone(), c, q, K, l, u, lp.m_ineq, eta, omega, 1.0)
+            xs.append(xn)
+            ys.append(yn)
+        lams = [ref_helpers.project_lambda_box(c - K.T @ yy, col(inn), col(ipn)) for yy in ys]
+        for tag, (a, b, lam_prev) in {"s01": (0, 1, lams[0]), "s12": (1, 2, lams[1]), "s23z": (2, 3, torch.zeros_like(lams[0])),
+                                      "same": (2, 2, lams[2])}.items():
+            st = [ref_enh.detect_infeasibility(xs[b], ys[b], xs[a], ys[a], lams[b], lam_prev, c, q, K, l, u, lp.m_ineq,
+                                               "cpu", tol=t) for t in tols]
+            put(out, f"op/{name}/{tag}", dict(x=xs[b].flatten().numpy(), y=ys[b].flatten().numpy(),
+                                             x_prev=xs[a].flatten().numpy(), y_prev=ys[a].flatten().numpy(),
+                                             lam_prev=lam_prev.flatten().numpy(), tols=np.array(tols),
+                                             status=np.array([s or "None" for s in st])))
+            print(f"G10 op/{name}/{tag}:", [s or "-" for s in st])
+    # (b) whole solves with the detector switched on
+    solves = dict(tiny_infeas_lps())
+    for name in ("mixed_27x32", "box_200x150", "mixed_200x260_allineq"):      # feasible, bounded: what the detector does to them
+        lp = cases[name]
+        solves[name] = (csr_to_dense(lp), lp.m_ineq, lp.c, lp.q, lp.l, lp.u)
+    for name, (K, m_ineq, c, q, l, u) in solves.items():
+        put(out, f"solve/{name}", dict(K=K.numpy(), m_ineq=m_ineq, c=c.numpy(), q=q.numpy(), l=l.numpy(), u=u.numpy()))
+        for adaptive in (False, True):
+            for itol in (1e-4, 1e-2):
+                torch.manual_seed(99)
+                b0 = torch.randn(K.shape[1], 1)
+                torch.manual_seed(99)
+                with contextlib.redirect_stdout(io.StringIO()):
+                    x, obj, k, n, j, status, _ = ref_pdhg.pdlp_algorithm(
+                        K, m_ineq, col(c), col(q), col(l), col(u), "cpu", max_kkt=20_000, tol=1e-4, verbose=False,
+                        restart_period=40, primal_update=adaptive, adaptive=adaptive, infeasibility_detect=True, infeas_tol=itol)
+                tag = f"solve/{name}/{'adaptive' if adaptive else 'fixed'}_{itol:g}"
+                put(out, tag, dict(b0=b0.flatten().numpy(), infeas_tol=itol, x=x.flatten().numpy(), obj=obj, k=k, n=n, j=j,
+                                   status=status))
+                print(f"G10 {tag}: k={k} n={n} j={j} {status} obj={obj:.6f}")
+    np.savez_compressed(os.path.join(HERE, "infeasibility.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"}
+    which = set(sys.argv[1:]) or {"g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"}
     cases = lp_cases()
     if "g1" in which: g1_step_fixed(cases)
     if "g2" in which: g2_step_adaptive(cases)
@@ -357,5 +430,6 @@ if __name__ == "__main__":
     if "g7" in which: g7_power_iter(cases)
     if "g8" in which: g8_mps()
     if "g9" in which: g9_afiro()
+    if "g10" in which: g10_infeasibility(cases)
     print("golden fixtures written to", HERE)
 

@@ -155,6 +155,27 @@ def _gpu_worker(rank, world, port, ret):
                 np.testing.assert_allclose(trace["kkt"][:nk], tr1["kkt"][:nk], rtol=5e-2 if adaptive else 1e-3)
                 assert trace["restarts"][:1] == tr1["restarts"][:1]
                 assert j == k + (len(trace["kkt"]) - n) + 2 * n
+        # the detector, sharded: dx, dy all-gathered, eight sums all-reduced -> the single-rank diagnostics
+        eng = shard_engine(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq, comm)
+        eng.set_iterate(torch.zeros(eng.nl, device=dev), torch.zeros(eng.ml, device=dev))
+        eng.set_step(0.05, 1.0, 1.0, 0)
+        eng.infeas_reset()
+        eng.iterate(2, True)
+        st2, d2 = eng.detect_infeasibility(1e-2, diagnostics=True)
+        eng.iterate(1, True)
+        st3, d3 = eng.detect_infeasibility(1e3, diagnostics=True)
+        del eng
+        if rank == 0:
+            e1 = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
+            e1.set_iterate(torch.zeros(lp.n, device=dev), torch.zeros(lp.m, device=dev))
+            e1.set_step(0.05, 1.0, 1.0, 0)
+            e1.iterate(2, True)
+            s2, f2 = e1.detect_infeasibility(1e-2, diagnostics=True)
+            e1.iterate(1, True)
+            s3, f3 = e1.detect_infeasibility(1e3, diagnostics=True)
+            assert (st2, st3) == (s2, s3)
+            np.testing.assert_allclose(d2, f2, rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(d3, f3, rtol=1e-4, atol=1e-5)
         # the user-facing entry point, sharded: every rank passes the whole problem and gets the whole solution
         res = tp.solve_lp((lp.c, K, lp.q, lp.m_ineq, lp.l, lp.u), device=dev, tol=1e-4, precondition=True,
                           primal_weight_update=True, adaptive_stepsize=True, seed=1, comm=True)

@@ -747,3 +747,85 @@ def test_tiled_kernel_random_shapes_match_csr():
         scale = np.abs(ref).max() + 1.0
         np.testing.assert_allclose(got / scale, ref / scale, rtol=0, atol=3e-6, err_msg=f"case {case}: m={m} n={n} lw={lw} rpt={t.rpt} groups={t.groups}")
     assert tried >= 12
+
+
+# ---------------------------------------------------------------------------------------------------
+# infeasibility detection (opt-in): pdlp_infeas_* against the oracle and the reference's recorded verdicts
+# ---------------------------------------------------------------------------------------------------
+def _set_pair(eng, x_prev, y_prev, x, y):
+    """make (x_prev, y_prev) PDLP_PREV and (x, y) PDLP_CUR: zero-step trick -- set the iterate, take one step that the
+    test then overwrites is not possible through the ABI, so both roles are written through the buffer views"""
+    eng.set_iterate(dev(x), dev(y))
+    eng.buffer(N.BUF_X_PREV)[:] = dev(x_prev)
+    eng.buffer(N.BUF_Y_PREV)[:] = dev(y_prev)
+
+
+@pytest.mark.parametrize("name", LP_CASES)
+@pytest.mark.parametrize("tag", ["s01", "s12", "s23z"])
+@pytest.mark.parametrize("tiled", [False, True])
+def test_detect_infeasibility_vs_oracle_and_golden(golden, name, tag, tiled):
+    from torchpdlp_amd.tiled import build_tiles
+    g = golden("infeasibility.npz")
+    a, K, o, eng = golden_lp(g, f"op/{name}")
+    if tiled:
+        for transpose, (rp, ci, va), rows, cols in ((0, eng.K, eng.ml, eng.n), (1, eng.KT, eng.nl, eng.m)):
+            t = build_tiles(rp, ci, va, rows, cols, lw=6)
+            assert t is not None
+            eng.attach_tiles(transpose, t)
+    r = g.group(f"op/{name}/{tag}")
+    for tol, want in zip(r["tols"], r["status"]):
+        _set_pair(eng, r["x_prev"], r["y_prev"], r["x"], r["y"])
+        eng.infeas_reset()
+        if tag != "s23z":     # lam_prev comes in through a first call on the previous pair's y: lam depends on y only
+            eng.buffer(N.BUF_Y_CUR)[:] = dev(r["y_prev"])
+            eng.detect_infeasibility(1.0)
+            eng.buffer(N.BUF_Y_CUR)[:] = dev(r["y"])
+        st, diag = eng.detect_infeasibility(float(tol), diagnostics=True)
+        so, lam, dgo = o.detect_infeasibility(r["x"], r["y"], r["x_prev"], r["y_prev"], r["lam_prev"], tol)
+        np.testing.assert_allclose(diag, dgo, rtol=3e-5, atol=3e-5)
+        margins = [abs(dgo[0] - tol), abs(dgo[2] - tol), abs(dgo[4] - tol), abs(dgo[6] - dgo[7] + tol)]
+        if min(margins) > 1e-4 * max(1.0, tol):           # (no threshold within rounding of the tested quantity)
+            assert (st or "None") == (so or "None") == str(want), (tol, diag)
+
+
+INFEAS_GPU_SOLVES = [(n, m) for n in ("primal_infeasible_box", "primal_infeasible_cone", "unbounded_ray", "unbounded_free_below",
+                                      "feasible_boxed", "feasible_mixed", "mixed_27x32", "box_200x150", "mixed_200x260_allineq")
+                     for m in ("fixed_0.0001", "fixed_0.01", "adaptive_0.0001", "adaptive_0.01")]
+
+
+@pytest.mark.parametrize("name,mode", INFEAS_GPU_SOLVES)
+def test_solve_with_infeasibility_detection(golden, name, mode):
+    """pdlp_algorithm(infeasibility_detect=True) against the reference's recorded runs (pdhg.py:89-101)"""
+    g = golden("infeasibility.npz")
+    a, r = g.group(f"solve/{name}"), g.group(f"solve/{name}/{mode}")
+    ad = mode.startswith("adaptive")
+    x, obj, k, n, j, status, _ = tp.pdlp_algorithm(dev(a["K"]), int(a["m_ineq"]), dev(a["c"]), dev(a["q"]), dev(a["l"]), dev(a["u"]),
+                                                   DEV, max_kkt=20_000, tol=1e-4, verbose=False, primal_update=ad, adaptive=ad,
+                                                   infeasibility_detect=True, infeas_tol=float(r["infeas_tol"]), b0=dev(r["b0"]))
+    tiny = name in ("primal_infeasible_box", "primal_infeasible_cone", "unbounded_ray", "unbounded_free_below", "feasible_boxed",
+                    "feasible_mixed")
+    if tiny or not ad:
+        assert status == str(r["status"])
+        assert abs(k - int(r["k"])) <= (0 if int(r["k"]) <= 2 else max(2, int(r["k"]) // 10)), (k, int(r["k"]))
+        if k == int(r["k"]):
+            assert (n, j) == (int(r["n"]), int(r["j"]))
+            np.testing.assert_allclose(x.cpu().numpy().ravel(), r["x"], rtol=2e-3, atol=2e-4)
+            assert abs(obj - float(r["obj"])) <= 2e-3 * (1 + abs(float(r["obj"])))
+    else:
+        assert status in ("Solved", "PRIMAL_INFEASIBLE", "DUAL_INFEASIBLE")
+        assert abs(obj - float(r["obj"])) <= 5e-3 * (1 + abs(float(r["obj"])))
+    if status != "Solved":
+        assert j == 2 * k - 1 + 3 * ((k - 1) // 40) + 2 * n      # the detector leaves before the restart check of its iteration
+
+
+def test_infeasibility_detection_off_is_untouched_and_on_counts_passes(golden):
+    """with the detector on and a tolerance it can never meet the iterates are those of the plain run; j grows by k - 1"""
+    g = golden("solve_trace.npz")
+    a, K, o, eng = golden_lp(g, "mixed_400x300")
+    r = g.group("mixed_400x300/fixed_pw")
+    args = (K, int(a["m_ineq"]), dev(a["c"]), dev(a["q"]), dev(a["l"]), dev(a["u"]), DEV)
+    kw = dict(tol=1e-4, verbose=False, primal_update=True, adaptive=False, b0=dev(r["b0"]))
+    x0, obj0, k0, n0, j0, st0, _ = tp.pdlp_algorithm(*args, **kw)
+    x1, obj1, k1, n1, j1, st1, _ = tp.pdlp_algorithm(*args, infeasibility_detect=True, infeas_tol=-1.0, **kw)
+    assert (k1, n1, st1) == (k0, n0, st0) and j1 == j0 + k0 - 1
+    assert torch.equal(x0, x1) and obj0 == obj1

@@ -84,6 +84,14 @@ class OracleEngine:
     def synchronize(self):
         pass
 
+    def infeas_reset(self):
+        self.lam_prev = np.zeros(self.o.n, np.float32)
+
+    def detect_infeasibility(self, tol):
+        st, lam, _ = self.o.detect_infeasibility(self.x, self.y, self.xp, self.yp, self.lam_prev, tol)
+        self.lam_prev = lam
+        return st
+
 
 def _lp(g, name):
     a = g.group(name)
@@ -169,3 +177,36 @@ def test_preconditioned_run_terminates_on_unscaled_residuals(golden):
     assert (k, n, j, status) == (ko, no, jo, so) and abs(obj - objo) <= 1e-5 * (1 + abs(objo))
     opt = float(g.group("mixed_400x300/fixed_nopw")["opt_obj"])
     assert abs(obj - opt) <= 2e-3 * (1 + abs(opt))
+
+
+@pytest.mark.parametrize("name", ["primal_infeasible_box", "unbounded_ray", "unbounded_free_below", "feasible_boxed", "feasible_mixed",
+                                  "mixed_27x32", "box_200x150"])
+@pytest.mark.parametrize("mode", ["fixed_0.0001", "fixed_0.01", "adaptive_0.0001", "adaptive_0.01"])
+def test_infeasibility_detection_in_the_driver(golden, name, mode):
+    """the product's loop with the detector on (pdhg.py:89-101): same exit, counters and status as the restated
+    reference loop, and as the reference's own recorded run where rounding cannot split them"""
+    g = golden("infeasibility.npz")
+    a, r = g.group(f"solve/{name}"), g.group(f"solve/{name}/{mode}")
+    o = orc.OracleLP.from_dense(a["K"], a["m_ineq"], a["c"], a["q"], a["l"], a["u"])
+    ad = mode.startswith("adaptive")
+    sig = float(o.power_iter(r["b0"], 100))
+    x, obj, k, n, j, status, _ = run_pdlp(OracleEngine(o), max_kkt=20_000, tol=1e-4, verbose=False, primal_update=ad, adaptive=ad,
+                                          sigma=sig, infeasibility_detect=True, infeas_tol=float(r["infeas_tol"]))
+    xo, objo, ko, no, jo, so, _, _ = orc.pdlp_algorithm(o, max_kkt=20_000, tol=1e-4, adaptive=ad, primal_update=ad, sigma=np.float32(sig),
+                                                          infeasibility_detect=True, infeas_tol=float(r["infeas_tol"]))
+    assert (k, n, j, status) == (ko, no, jo, so)
+    assert abs(obj - objo) <= 1e-5 * (1 + abs(objo))
+    np.testing.assert_allclose(x.numpy(), xo, rtol=1e-6, atol=1e-7)
+    if not ad or not name[0] in "mb":
+        assert (k, n, j, status) == (int(r["k"]), int(r["n"]), int(r["j"]), str(r["status"]))
+
+
+def test_infeasibility_detection_respects_the_pass_cap(golden):
+    g = golden("infeasibility.npz")
+    a = g.group("solve/mixed_27x32")
+    o = orc.OracleLP.from_dense(a["K"], a["m_ineq"], a["c"], a["q"], a["l"], a["u"])
+    sig = float(o.power_iter(g.group("solve/mixed_27x32/fixed_0.0001")["b0"], 100))
+    for cap in (1, 2, 7, 50, 101):
+        got = run_pdlp(OracleEngine(o), max_kkt=cap, verbose=False, sigma=sig, infeasibility_detect=True, infeas_tol=1e-9)
+        want = orc.pdlp_algorithm(o, max_kkt=cap, sigma=np.float32(sig), infeasibility_detect=True, infeas_tol=1e-9)
+        assert got[2:6] == want[2:6]

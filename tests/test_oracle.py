@@ -201,3 +201,44 @@ def test_solve_tiny_known_answer(golden, mode):
     assert (k, n, j, status) == (int(r["k"]), int(r["n"]), int(r["j"]), str(r["status"])) == (40, 1, 45, "Solved")
     np.testing.assert_allclose(x, r["x"], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(obj, r["obj"], rtol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------
+# infeasibility detection (opt-in): detect_infeasibility enhancements.py:80-161, driven from pdhg.py:89-101
+# ---------------------------------------------------------------------------------------------------
+INFEAS_SOLVES = ["primal_infeasible_box", "primal_infeasible_cone", "unbounded_ray", "unbounded_free_below", "feasible_boxed",
+                 "feasible_mixed", "mixed_27x32", "box_200x150", "mixed_200x260_allineq"]
+
+
+@pytest.mark.parametrize("name", LP_CASES)
+@pytest.mark.parametrize("tag", ["s01", "s12", "s23z", "same"])
+def test_detect_infeasibility_decisions(golden, name, tag):
+    """the detector's verdict over a ladder of tolerances (every threshold test flips somewhere along it)"""
+    g = golden("infeasibility.npz")
+    lp = lp_from(g, f"op/{name}")
+    r = g.group(f"op/{name}/{tag}")
+    for tol, want in zip(r["tols"], r["status"]):
+        if tag == "same" and tol < 1e-4:
+            continue        # dx = dy = dlam = 0 up to the rounding of lam itself (the generator computed it with a dense K)
+        st, lam, diag = lp.detect_infeasibility(r["x"], r["y"], r["x_prev"], r["y_prev"], r["lam_prev"], tol)
+        assert (st or "None") == str(want), (tol, diag)
+
+
+@pytest.mark.parametrize("name", INFEAS_SOLVES)
+@pytest.mark.parametrize("mode", ["fixed_0.0001", "fixed_0.01", "adaptive_0.0001", "adaptive_0.01"])
+def test_solve_with_infeasibility_detection_follows_the_reference(golden, name, mode):
+    g = golden("infeasibility.npz")
+    a, r = g.group(f"solve/{name}"), g.group(f"solve/{name}/{mode}")
+    lp = orc.OracleLP.from_dense(a["K"], a["m_ineq"], a["c"], a["q"], a["l"], a["u"])
+    ad = mode.startswith("adaptive")
+    x, obj, k, n, j, st, _, _ = orc.pdlp_algorithm(lp, max_kkt=20_000, tol=1e-4, adaptive=ad, primal_update=ad,
+                                                   infeasibility_detect=True, infeas_tol=float(r["infeas_tol"]), b0=r["b0"])
+    if name in INFEAS_SOLVES[:6] or not ad:
+        assert (k, n, j, st) == (int(r["k"]), int(r["n"]), int(r["j"]), str(r["status"]))
+        assert abs(obj - float(r["obj"])) <= 1e-4 * (1 + abs(float(r["obj"])))
+    else:       # long adaptive runs part ways with the reference through rounding (DESIGN.md section 6): on these feasible
+        #         LPs it is a race between convergence and the detector's misfire on stalled iterates; both end at the optimum
+        assert st in ("Solved", "PRIMAL_INFEASIBLE", "DUAL_INFEASIBLE") and abs(k - int(r["k"])) <= 0.6 * int(r["k"]) + 80
+        assert abs(obj - float(r["obj"])) <= 5e-3 * (1 + abs(float(r["obj"])))
+    if st in ("DUAL_INFEASIBLE", "PRIMAL_INFEASIBLE"):
+        assert j == 2 * k - 1 + 3 * ((k - 1) // 40) + 2 * n      # a pass per step, a detector pass from k = 2, restart checks before k

@@ -71,12 +71,11 @@ def main(argv=None) -> int:
         path = os.path.join(args.instance_path, name)
         print(f"\nProcessing {path}...")
         try:
-            if args.infeasibility_detect:
-                raise NotImplementedError("infeasibility detection is outside the accelerated hot path")
             r = solve_lp(path, tol=args.tolerance, precondition=args.precondition, primal_weight_update=args.primal_weight_update,
                          adaptive_stepsize=args.adaptive_stepsize, max_kkt=args.max_kkt, time_limit=args.time_limit,
                          verbose=args.verbose, dtype=torch.float32 if args.dtype == "fp32" else torch.float64, seed=args.seed,
-                         compat=not args.standard_mps, fishnet=args.fishnet, comm=comm)
+                         compat=not args.standard_mps, fishnet=args.fishnet, comm=comm,
+                         infeasibility_detect=args.infeasibility_detect)
             print(f"Solver uses {r.time:.4f} seconds.\nStatus: {r.status}")
             results.append({"File": name, "Objective": f"{r.objective:.6f}", "Iterations (k)": r.iterations, "Restarts (n)": r.restarts,
                             "KKT Passes (j)": r.kkt_passes, "Time (s)": f"{r.time:.4f}", "Status": r.status})      # main.py:142-150

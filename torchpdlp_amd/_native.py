@@ -11,11 +11,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PDLP_LIB", os.path.join(_HERE, "libpdlp_hip.so"))   # PDLP_LIB: profiling/ablation builds
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 PDLP_F32, PDLP_F64 = 0, 1
 CUR, AVG, PREV = 0, 1, 2
 (BUF_X_CUR, BUF_X_PREV, BUF_XBAR, BUF_X_AVG, BUF_Y_CUR, BUF_Y_PREV, BUF_Y_AVG, BUF_RED, BUF_X_SUM, BUF_Y_SUM,
- BUF_SCALARS) = range(11)
+ BUF_SCALARS, BUF_DX, BUF_DY) = range(13)
 NRED, NSCAL = 8, 16
 # indices into the scalar block
 S_ETA, S_OMEGA, S_THETA, S_TAU, S_SIGMA, S_WPEND, S_ETASUM, S_K, S_INV1PT, S_ACCEPT, S_ETABAR, S_DEN = range(12)
@@ -70,6 +70,10 @@ SIGNATURES = {
     "pdlp_restart_distance_local": (_I, [_H]),
     "pdlp_mark_restart_point": (_I, [_H]),
     "pdlp_read_red": (_I, [_H, C.POINTER(_D)]),
+    "pdlp_infeas_reset": (_I, [_H]),
+    "pdlp_infeas_begin": (_I, [_H]),
+    "pdlp_infeas_local": (_I, [_H, _D]),
+    "pdlp_infeas_finish": (_I, [_H, _D, C.POINTER(C.c_int32), C.POINTER(_D)]),
     "pdlp_spmv": (_I, [_H, _I, _P, _P]),
     "pdlp_power_iteration": (_I, [_H, _P, _I, _P, _P, C.POINTER(_D)]),
     "pdlp_csr_row_scale_factors": (_I, [_I, _I64, _P, _P, _D, _P, _P]),

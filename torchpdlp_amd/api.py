@@ -23,6 +23,7 @@ class LPResult:
     restarts: int              # n
     kkt_passes: int            # j
     status: str                # "Solved" | "Unsolved (KKT passes limit exceeded)" | "Unsolved (Time limit exceeded)"
+                               # | "DUAL_INFEASIBLE" | "PRIMAL_INFEASIBLE" (only with infeasibility_detect)
     time: float                # seconds, preconditioning included (main.py:107,136)
 
     def as_tuple(self):
@@ -34,12 +35,13 @@ def solve_lp(problem: Union[str, os.PathLike, tuple], device=None, tol: float = 
              primal_weight_update: bool = False, adaptive_stepsize: bool = False, max_kkt: int = 100_000,
              time_limit: float = 3600, verbose: bool = False, restart_period: int = 40, dtype=torch.float32,
              seed: Optional[int] = None, compat: bool = True, x_init=None, y_init=None, trace=None,
-             fishnet: bool = False, comm=None) -> LPResult:
+             fishnet: bool = False, comm=None, infeasibility_detect: bool = False, infeas_tol: float = 1e-4) -> LPResult:
     """Solve ``min c'x, K[:m_ineq]x >= q[:m_ineq], K[m_ineq:]x = q[m_ineq:], l <= x <= u`` on the current HIP device.
 
     ``problem`` is an MPS path or ``(c, K, q, m_ineq, l, u)`` with ``K`` dense / COO / scipy-sparse / ``CsrPair``.
     Flags carry the reference CLI's names (main.py:11-39).  ``dtype=torch.float64`` is the mode for tolerances
-    below float32 resolution (the reference is float32 only).  Under ``torchrun`` (one process per GPU, process
+    below float32 resolution (the reference is float32 only).  ``infeasibility_detect`` runs the reference's detector
+    (enhancements.py:80-161) after every iteration, with its behaviour as it is.  Under ``torchrun`` (one process per GPU, process
     group initialised) pass ``comm=True``: every rank reads the same problem, keeps its row blocks of K and K', and
     all return the full solution.
     """
@@ -64,7 +66,7 @@ def solve_lp(problem: Union[str, os.PathLike, tuple], device=None, tol: float = 
         Ks, m_ineq, cs, qs, ls, us, device, max_kkt=max_kkt, tol=tol, verbose=verbose, restart_period=restart_period,
         precondition=precondition, primal_update=primal_weight_update, adaptive=adaptive_stepsize,
         data_precond=data_precond, time_limit=time_limit, time_used=time_used, x_init=x_init, y_init=y_init, seed=seed,
-        trace=trace, comm=comm)
+        trace=trace, comm=comm, infeasibility_detect=infeasibility_detect, infeas_tol=infeas_tol)
     if precondition:        # the reference returns the scaled iterate (quirk Q4); solve_lp un-scales: x = D_col x_s (pdhg.py:161)
         x = data_precond[0].view(-1, 1).to(x.dtype) * x
     return LPResult(x, obj, k, n, j, status, total)

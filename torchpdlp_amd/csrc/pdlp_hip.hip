@@ -192,6 +192,60 @@ template <typename T, bool UNSCALE> struct KktPrimalEpi {
     }
 };
 
+// infeasibility detection (opt-in), variable side -- detect_infeasibility enhancements.py:108-114,124-139,146-157 for
+// the step just taken, with lam = project_lambda_box(c - K'y) (pdhg.py:90, helpers.py:21-37).  Rows of K'.
+// partial sums: ||K'dy - dlam||^2, l_f'dlam_minus + u_f'dlam_plus, c'dx, #{variables failing the bound test}
+template <typename T> struct InfeasDualEpi {
+    static constexpr int NA = 4;
+    const T* x; const T* x_prev; const T* c; const T* l; const T* u; const T* ktdy; T* lam_prev; T tol;
+    __device__ void load() {}
+    __device__ void operator()(int j, T kty, double* acc) const
+    {
+        const T cj = c[j], lo = l[j], hi = u[j];
+        const T g = cj - kty;
+        const bool ninf = isinf(lo) && lo < (T)0, pinf = isinf(hi) && hi > (T)0;
+        T lam;
+        if (ninf && pinf) lam = (T)0;
+        else if (ninf) lam = g < (T)0 ? g : (T)0;
+        else if (pinf) lam = g > (T)0 ? g : (T)0;
+        else lam = g;
+        const T dlam = lam - lam_prev[j];                                    // :110
+        lam_prev[j] = lam;                                                   // pdhg.py:101
+        const T r = ktdy[j] - dlam;                                          // :146
+        acc[0] += (double)r * (double)r;
+        const T plus = -dlam > (T)0 ? -dlam : (T)0, minus = dlam > (T)0 ? dlam : (T)0;   // :113-114
+        double lu = 0.0;
+        if (!isinf(lo) && lo != (T)0) lu += (double)lo * (double)minus;      // :151,155
+        if (!isinf(hi) && hi != (T)0) lu += (double)hi * (double)plus;       // :152,157
+        acc[1] += lu;
+        const T d = x[j] - x_prev[j];                                        // :108
+        acc[2] += (double)cj * (double)d;                                    // :124
+        const T ad = d < (T)0 ? -d : d;
+        const bool ok = (!isinf(lo) && !isinf(hi) && ad <= tol) || (pinf && cj >= (T)0 && d >= -tol) ||
+                        (ninf && cj <= (T)0 && d <= tol);                    // :135-137
+        acc[3] += ok ? 0.0 : 1.0;
+    }
+};
+
+// infeasibility detection, constraint side (rows of K): kdx = (K dx)_i.  enhancements.py:118,121,148-149
+// partial sums: ||K_eq dx||^2, #{(K_in dx)_i < -tol}, #{dy_i < -tol, i inequality}, q'dy
+template <typename T> struct InfeasPrimalEpi {
+    static constexpr int NA = 4;
+    const T* y; const T* y_prev; const T* q; T tol; int ineq_end;
+    __device__ void load() {}
+    __device__ void operator()(int i, T kdx, double* acc) const
+    {
+        const T dy = y[i] - y_prev[i];                                       // :109
+        if (i < ineq_end) {
+            acc[1] += (kdx >= -tol) ? 0.0 : 1.0;
+            acc[2] += (dy >= -tol) ? 0.0 : 1.0;
+        } else {
+            acc[0] += (double)kdx * (double)kdx;
+        }
+        acc[3] += (double)q[i] * (double)dy;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // the fused CSR kernel
 // ------------------------------------------------------------------------------------------------
@@ -680,6 +734,13 @@ __global__ __launch_bounds__(BLOCK) void k_average(int64_t n, T* __restrict__ av
 
 __global__ void k_clear_pending(double* sc) { sc[S_WPEND] = 0.0; }
 
+// out = a - b
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_sub(int64_t n, T* __restrict__ out, const T* __restrict__ a, const T* __restrict__ b)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) out[i] = a[i] - b[i];
+}
+
 // partials[b][0] = sum (a-b)^2 (b may be null: sum a^2)
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_sqdiff(int64_t n, const T* __restrict__ a, const T* __restrict__ b,
@@ -867,6 +928,8 @@ struct pdlp_solver {
     char* xbar;
     char *x_sum, *y_sum, *x_last, *y_last;
     char* kxb[3];                 // K x caches: [0] running, [1] from KKT(cur), [2] from KKT(avg)
+    char *dxf, *dyf;              // infeasibility detection: full-length x - x_prev, y - y_prev (gathered by the caller when sharded)
+    char *lam_prev, *ktdy;        //   this rank's block of the previous lambda and of K'dy
     bool kx_valid, cand_valid[2];
     double *partA, *partB, *red, *sc;
     void* rowsum;                 // row sums of the tiled kernel on their way to the epilogue: [groups][rs_stride]
@@ -1154,6 +1217,47 @@ template <typename T> int spmv_t(pdlp_handle h, int transpose, const void* in_fu
     return launch_csr<T>(h, transpose != 0, in_full, e, h->partA);
 }
 
+// dx, dy of the step just taken (cur vs prev) into this rank's blocks of the full-length buffers
+template <typename T> int infeas_begin_t(pdlp_handle h)
+{
+    if (h->nl > 0)
+        hipLaunchKernelGGL(k_sub<T>, dim3(grid_for(h->nl)), dim3(BLOCK), 0, h->stream, h->nl, (T*)h->dxf + h->p.col0,
+                           (const T*)xloc<T>(h, h->ix_cur), (const T*)xloc<T>(h, h->ix_prev));
+    if (h->ml > 0)
+        hipLaunchKernelGGL(k_sub<T>, dim3(grid_for(h->ml)), dim3(BLOCK), 0, h->stream, h->ml, (T*)h->dyf + h->p.row0,
+                           (const T*)yloc<T>(h, h->ix_cur), (const T*)yloc<T>(h, h->ix_prev));
+    HIP_TRY(hipGetLastError());
+    return PDLP_OK;
+}
+
+// three products (K'dy, K'y with the variable-side tests fused, K dx with the constraint-side tests fused) and the
+// eight partial sums of detect_infeasibility into red[0..7]
+template <typename T> int infeas_local_t(pdlp_handle h, double tol)
+{
+    int rc;
+    if ((rc = spmv_t<T>(h, 1, h->dyf, h->ktdy)) != PDLP_OK) return rc;
+    InfeasDualEpi<T> ed{xloc<T>(h, h->ix_cur), xloc<T>(h, h->ix_prev), (const T*)h->p.c, (const T*)h->p.l, (const T*)h->p.u,
+                        (const T*)h->ktdy, (T*)h->lam_prev, (T)tol};
+    if ((rc = launch_csr<T>(h, true, h->yb[h->ix_cur], ed, h->partA)) != PDLP_OK) return rc;
+    InfeasPrimalEpi<T> ep{yloc<T>(h, h->ix_cur), yloc<T>(h, h->ix_prev), (const T*)h->p.q, (T)tol, h->ineq_end};
+    if ((rc = launch_csr<T>(h, false, h->dxf, ep, h->partB)) != PDLP_OK) return rc;
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partA, grid_of(h->sKT, h->nl), 4, h->red, 0);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partB, grid_of(h->sK, h->ml), 4, h->red, 4);
+    HIP_TRY(hipGetLastError());
+    return PDLP_OK;
+}
+
+// the decisions of enhancements.py:118-142 and :148-159 from the eight sums, in the working precision
+template <typename T> int infeas_decide_t(const double* r, double tol, double* diag)
+{
+    const T t = (T)tol;
+    const T dres = (T)std::sqrt(r[0]), lu = (T)r[1], cdx = (T)r[2], eqn = (T)std::sqrt(r[4]), qdy = (T)r[7];
+    diag[0] = eqn; diag[1] = r[5]; diag[2] = cdx; diag[3] = r[3]; diag[4] = dres; diag[5] = r[6]; diag[6] = qdy; diag[7] = lu;
+    if (eqn < t && r[5] == 0.0 && cdx < t && r[3] == 0.0) return 1;                      // "DUAL_INFEASIBLE"
+    if (dres < t && r[6] == 0.0 && (double)qdy - (double)lu > -tol) return 2;            // "PRIMAL_INFEASIBLE"
+    return 0;
+}
+
 template <typename T> int power_iteration_t(pdlp_handle h, const void* b0, int iters, void* work_n, void* work_m, double* sigma)
 {
     T* b = (T*)work_n;
@@ -1205,7 +1309,7 @@ struct Carve {
 };
 
 // one layout function used by both the size query and pdlp_create
-int64_t layout(const pdlp_problem* p, int64_t nnzK, int64_t nnzKT, int64_t* offs /*[32]*/)
+int64_t layout(const pdlp_problem* p, int64_t nnzK, int64_t nnzKT, int64_t* offs /*[40]*/)
 {
     const int64_t es = p->dtype == PDLP_F32 ? 4 : 8;
     const int64_t nl = p->col1 - p->col0, ml = p->row1 - p->row0;
@@ -1234,6 +1338,10 @@ int64_t layout(const pdlp_problem* p, int64_t nnzK, int64_t nnzKT, int64_t* offs
         offs[k++] = c.take((max_long(nnz) + 1) * 4);              //   chunk ranges
         offs[k++] = c.take(max_chunks(nnz) * es);                 //   chunk sums
     }
+    offs[k++] = c.take(p->n * es);                                // 29    dx (infeasibility detection)
+    offs[k++] = c.take(p->m * es);                                // 30    dy
+    offs[k++] = c.take(nl * es);                                  // 31    lam_prev
+    offs[k++] = c.take(nl * es);                                  // 32    K'dy
     return c.off;
 }
 
@@ -1252,7 +1360,7 @@ int read_last_rowptr(const int32_t* rp, int64_t rows, int64_t* nnz)
 // ================================================================================================
 extern "C" {
 
-int pdlp_abi_version(void) { return 2; }   // 2: tile count words map lanes to wave-consecutive rows
+int pdlp_abi_version(void) { return 3; }   // 3: infeasibility detection entry points, PDLP_BUF_DX/DY
 
 const char* pdlp_strerror(int code)
 {
@@ -1272,7 +1380,7 @@ int pdlp_workspace_bytes(const pdlp_problem* p, int64_t* bytes)
     int rc = check_problem(p);
     if (rc != PDLP_OK || !bytes) return PDLP_ERR_INVALID;
     HIP_TRY(hipSetDevice(p->device));
-    int64_t nnzK = 0, nnzKT = 0, offs[32];
+    int64_t nnzK = 0, nnzKT = 0, offs[40];
     if ((rc = read_last_rowptr(p->K_rowptr, p->row1 - p->row0, &nnzK)) != PDLP_OK) return rc;
     if ((rc = read_last_rowptr(p->KT_rowptr, p->col1 - p->col0, &nnzKT)) != PDLP_OK) return rc;
     *bytes = layout(p, nnzK, nnzKT, offs);
@@ -1289,7 +1397,7 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     if (ml > 0) HIP_TRY(hipMemcpy(rpK.data(), p->K_rowptr, (size_t)(ml + 1) * 4, hipMemcpyDeviceToHost));
     if (nl > 0) HIP_TRY(hipMemcpy(rpKT.data(), p->KT_rowptr, (size_t)(nl + 1) * 4, hipMemcpyDeviceToHost));
     if (rpK[0] != 0 || rpKT[0] != 0) return PDLP_ERR_INVALID;
-    int64_t offs[32];
+    int64_t offs[40];
     const int64_t need = layout(p, rpK[ml], rpKT[nl], offs);
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255u)) return PDLP_ERR_WORKSPACE;
 
@@ -1313,6 +1421,7 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     h->red = (double*)(w + offs[16]); h->sc = (double*)(w + offs[17]);
     h->sK.blk = (int32_t*)(w + offs[18]); h->sKT.blk = (int32_t*)(w + offs[19]);
     h->rowsum = (void*)(w + offs[20]);
+    h->dxf = w + offs[29]; h->dyf = w + offs[30]; h->lam_prev = w + offs[31]; h->ktdy = w + offs[32];
     h->rs_stride = (nl > ml ? nl : ml) + (int64_t)TNT * TRPT_MAX_ANY;
     h->rs_groups = (int)rowsum_groups(nl > ml ? nl : ml);
     h->kx_valid = false; h->cand_valid[0] = h->cand_valid[1] = false;
@@ -1363,6 +1472,7 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     }
     // zero every state vector, scratch and scalar (everything in front of the schedules)
     if (rc == PDLP_OK && hipMemsetAsync(w, 0, (size_t)offs[18], h->stream) != hipSuccess) rc = PDLP_ERR_HIP_BASE - 1;
+    if (rc == PDLP_OK && hipMemsetAsync(w + offs[29], 0, (size_t)(need - offs[29]), h->stream) != hipSuccess) rc = PDLP_ERR_HIP_BASE - 1;
     if (rc != PDLP_OK) { free_handle(h); return rc; }
     if (p->dtype == PDLP_F32) hipLaunchKernelGGL(k_set_step<float>, dim3(1), dim3(1), 0, h->stream, h->sc, 0.0, 1.0, 1.0, 0.0);
     else hipLaunchKernelGGL(k_set_step<double>, dim3(1), dim3(1), 0, h->stream, h->sc, 0.0, 1.0, 1.0, 0.0);
@@ -1392,6 +1502,8 @@ int pdlp_buffer_ptr(pdlp_handle h, int which, void** ptr)
         case PDLP_BUF_X_SUM: *ptr = h->x_sum; break;
         case PDLP_BUF_Y_SUM: *ptr = h->y_sum; break;
         case PDLP_BUF_SCALARS: *ptr = h->sc; break;
+        case PDLP_BUF_DX: *ptr = h->dxf; break;
+        case PDLP_BUF_DY: *ptr = h->dyf; break;
         default: return PDLP_ERR_INVALID;
     }
     return PDLP_OK;
@@ -1704,6 +1816,35 @@ int pdlp_mark_restart_point(pdlp_handle h)
     if (!h) return PDLP_ERR_INVALID;                                          // pdhg.py:63-64
     HIP_TRY(hipMemcpyAsync(h->x_last, h->xb[h->ix_cur] + h->p.col0 * h->es, h->nl * h->es, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->y_last, h->yb[h->ix_cur] + h->p.row0 * h->es, h->ml * h->es, hipMemcpyDeviceToDevice, h->stream));
+    return PDLP_OK;
+}
+
+int pdlp_infeas_reset(pdlp_handle h)
+{
+    if (!h) return PDLP_ERR_INVALID;
+    HIP_TRY(hipMemsetAsync(h->lam_prev, 0, h->nl * h->es, h->stream));          // pdhg.py:39-40
+    return PDLP_OK;
+}
+
+int pdlp_infeas_begin(pdlp_handle h)
+{
+    if (!h) return PDLP_ERR_INVALID;
+    return DISPATCH(h, infeas_begin_t, h);
+}
+
+int pdlp_infeas_local(pdlp_handle h, double tol)
+{
+    if (!h) return PDLP_ERR_INVALID;
+    return DISPATCH(h, infeas_local_t, h, tol);
+}
+
+int pdlp_infeas_finish(pdlp_handle h, double tol, int32_t* status, double diag[8])
+{
+    if (!h || !status || !diag) return PDLP_ERR_INVALID;
+    double r[PDLP_NRED];
+    const int rc = pdlp_read_red(h, r);
+    if (rc != PDLP_OK) return rc;
+    *status = h->p.dtype == PDLP_F32 ? infeas_decide_t<float>(r, tol, diag) : infeas_decide_t<double>(r, tol, diag);
     return PDLP_OK;
 }
 

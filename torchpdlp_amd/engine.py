@@ -179,7 +179,7 @@ class PdlpEngine:
                 cnt = N.NRED if which == N.BUF_RED else N.NSCAL
                 v = self.workspace[off:off + cnt * 8].view(torch.float64)
             else:
-                ln = {N.BUF_X_SUM: self.nl, N.BUF_Y_SUM: self.ml}.get(
+                ln = {N.BUF_X_SUM: self.nl, N.BUF_Y_SUM: self.ml, N.BUF_DX: self.n, N.BUF_DY: self.m}.get(
                     which, self.n if which <= N.BUF_X_AVG else self.m)
                 v = self.workspace[off:off + ln * self.dtype.itemsize].view(self.dtype)
             self._views[key] = v
@@ -276,6 +276,28 @@ class PdlpEngine:
 
     def mark_restart_point(self):
         N.check(self.lib.pdlp_mark_restart_point(self.h), "pdlp_mark_restart_point")
+
+    # ---- infeasibility detection (opt-in) ---------------------------------------------------------------
+    INFEAS_STATUS = (None, "DUAL_INFEASIBLE", "PRIMAL_INFEASIBLE")          # enhancements.py:142,159,161
+
+    def infeas_reset(self):
+        """lam_prev = 0 (pdhg.py:39-40)"""
+        N.check(self.lib.pdlp_infeas_reset(self.h), "pdlp_infeas_reset")
+
+    def detect_infeasibility(self, tol: float, diagnostics: bool = False):
+        """detect_infeasibility (enhancements.py:80-161) for the step just taken, including the lambda of
+        pdhg.py:90 and the lam_prev update of pdhg.py:101.  Returns the reference's status string or None."""
+        N.check(self.lib.pdlp_infeas_begin(self.h), "pdlp_infeas_begin")
+        if self.comm is not None:
+            self.comm.all_gather(self.buffer(N.BUF_DX))
+            self.comm.all_gather(self.buffer(N.BUF_DY))
+        N.check(self.lib.pdlp_infeas_local(self.h, float(tol)), "pdlp_infeas_local")
+        if self.comm is not None:
+            self.comm.all_reduce_sum(self.buffer(N.BUF_RED))
+        st, diag = C.c_int32(0), (C.c_double * 8)()
+        N.check(self.lib.pdlp_infeas_finish(self.h, float(tol), C.byref(st), diag), "pdlp_infeas_finish")
+        status = self.INFEAS_STATUS[st.value]
+        return (status, list(diag)) if diagnostics else status
 
     # ---- products -----------------------------------------------------------------------------------
     def spmv(self, v_full: torch.Tensor, transpose: bool = False) -> torch.Tensor:

@@ -70,8 +70,10 @@ class PdhgDriver:
     """
 
     def __init__(self, eng: PdlpEngine, restart_period=40, primal_update=False, adaptive=False, precondition=False,
-                 tol=1e-4, verbose=False, trace=None):
+                 tol=1e-4, verbose=False, trace=None, infeasibility_detect=False, infeas_tol=1e-4):
         self.eng, self.period = eng, int(restart_period)
+        self.infeasibility_detect, self.infeas_tol = bool(infeasibility_detect), float(infeas_tol)
+        self.infeasible = None                                              # the detector's verdict (pdhg.py:94-100)
         self.primal_update, self.adaptive, self.precondition = bool(primal_update), bool(adaptive), bool(precondition)
         self.tol, self.verbose, self.trace = tol, verbose, trace
         self.t = _np_t(eng.dtype)
@@ -95,22 +97,45 @@ class PdhgDriver:
         else:
             eng.set_iterate(zeros(eng.nl), zeros(eng.ml))
         eng.set_step(eta, self.omega, theta, 0)
+        if self.infeasibility_detect:
+            eng.infeas_reset()                                              # pdhg.py:39-40
         self.n = self.k = self.j = self.tt = 0
         self.KKT_first = t(0)
-        self.res, self.solved = None, False
+        self.res, self.solved, self.infeasible = None, False, None
 
     def advance(self, max_iters: int) -> int:
         """Iterate up to the next restart check (at most ``max_iters``); returns the iterations done."""
         eng, t = self.eng, self.t
-        iters = min(self.period - self.tt % self.period, int(max_iters))
-        if iters <= 0:
-            return 0
-        eng.iterate(iters, self.adaptive)                                   # pdhg.py:76-112
-        self.k += iters
-        self.j += iters
-        self.tt += iters
-        if self.tt % self.period != 0:                                      # pdhg.py:115
-            return iters
+        if self.infeasibility_detect:
+            # the detector looks at every iterate (pdhg.py:89-101): one iteration per call, one more pass each
+            iters, j0 = 0, self.j
+            while True:
+                eng.iterate(1, self.adaptive)
+                self.k += 1
+                self.j += 1
+                iters += 1
+                if self.k > 1:                                              # "need at least two points"
+                    self.infeasible = eng.detect_infeasibility(self.infeas_tol)
+                    self.j += 1                                             # pdhg.py:93
+                    if self.infeasible:
+                        if self.verbose:
+                            print(f"[PDLP] {self.infeasible} detected at iteration {self.k}")
+                        return iters
+                self.tt += 1
+                if self.tt % self.period == 0:
+                    break
+                if self.j - j0 >= int(max_iters):                           # pdhg.py:67
+                    return iters
+        else:
+            iters = min(self.period - self.tt % self.period, int(max_iters))
+            if iters <= 0:
+                return 0
+            eng.iterate(iters, self.adaptive)                               # pdhg.py:76-112
+            self.k += iters
+            self.j += iters
+            self.tt += iters
+            if self.tt % self.period != 0:                                  # pdhg.py:115
+                return iters
         if self.adaptive:
             eng.flush_average()
         eng.compute_average()                                               # pdhg.py:118-119
@@ -191,10 +216,11 @@ def estimate_sigma(eng: PdlpEngine, b0=None, power_iters=100, seed=None) -> floa
 
 def run_pdlp(eng: PdlpEngine, max_kkt=100_000, tol=1e-4, verbose=True, restart_period=40, precondition=False,
              primal_update=False, adaptive=False, time_limit=3600, time_used=0, x_init=None, y_init=None,
-             b0=None, sigma=None, power_iters=100, seed=None, trace=None):
+             b0=None, sigma=None, power_iters=100, seed=None, trace=None, infeasibility_detect=False, infeas_tol=1e-4):
     """The outer loop over an existing engine.  Returns (x_local, prim_obj, k, n, j, status, total_time)."""
     t0 = time.time()
-    drv = PdhgDriver(eng, restart_period, primal_update, adaptive, precondition, tol, verbose, trace)
+    drv = PdhgDriver(eng, restart_period, primal_update, adaptive, precondition, tol, verbose, trace,
+                     infeasibility_detect, infeas_tol)
     if sigma is None:                                                       # pdhg.py:22
         sigma = estimate_sigma(eng, b0, power_iters, seed)
     drv.start(sigma, x_init, y_init)
@@ -213,6 +239,12 @@ def run_pdlp(eng: PdlpEngine, max_kkt=100_000, tol=1e-4, verbose=True, restart_p
                     print("Time limit exceeded")
                 break
             drv.advance(max_kkt - drv.j)
+            if drv.infeasible:
+                break
+        if drv.infeasible:                                                  # pdhg.py:94-100: leave at once with c'x
+            status = drv.infeasible
+            drv.res = eng.kkt(N.CUR, drv.omega)
+            break
         if status == STATUS_TIME_LIMIT:
             break
         if drv.n == n_before:        # left the inner loop through the KKT-pass cap (pdhg.py:67 -> :148)
@@ -245,8 +277,6 @@ def pdlp_algorithm(K, m_ineq, c, q, l, u, device=None, max_kkt=100_000, tol=1e-4
     full problem and the same ``seed``/``b0``; each keeps its row blocks of K and K', the iterations exchange
     ``xbar`` and ``y`` over RCCL, and every rank returns the full solution.
     """
-    if infeasibility_detect:
-        raise NotImplementedError("infeasibility detection is outside the accelerated hot path (SURVEY.md 8f row f4)")
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     if device.type == "cuda" and device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
@@ -277,9 +307,11 @@ def pdlp_algorithm(K, m_ineq, c, q, l, u, device=None, max_kkt=100_000, tol=1e-4
         verbose = verbose and comm.rank == 0
         x, obj, k, n, j, status, total = run_pdlp(eng, max_kkt, tol, verbose, restart_period, precondition, primal_update,
                                                   adaptive, time_limit, time_used, x_init, y_init, b0=b0, sigma=sigma,
-                                                  seed=seed, trace=trace)
+                                                  seed=seed, trace=trace, infeasibility_detect=infeasibility_detect,
+                                                  infeas_tol=infeas_tol)
         return gather_solution(eng, x, Kp.n).view(-1, 1), obj, k, n, j, status, total
     eng = PdlpEngine.from_full(Kp, c, q, l, u, m_ineq, d_col=d_col, d_row=d_row)
     x, obj, k, n, j, status, total = run_pdlp(eng, max_kkt, tol, verbose, restart_period, precondition, primal_update, adaptive,
-                                              time_limit, time_used, x_init, y_init, b0=b0, sigma=sigma, seed=seed, trace=trace)
+                                              time_limit, time_used, x_init, y_init, b0=b0, sigma=sigma, seed=seed, trace=trace,
+                                              infeasibility_detect=infeasibility_detect, infeas_tol=infeas_tol)
     return x.view(-1, 1), obj, k, n, j, status, total
