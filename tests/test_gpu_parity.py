@@ -829,3 +829,4 @@ def test_infeasibility_detection_off_is_untouched_and_on_counts_passes(golden):
     x1, obj1, k1, n1, j1, st1, _ = tp.pdlp_algorithm(*args, infeasibility_detect=True, infeas_tol=-1.0, **kw)
     assert (k1, n1, st1) == (k0, n0, st0) and j1 == j0 + k0 - 1
     assert torch.equal(x0, x1) and obj0 == obj1
+

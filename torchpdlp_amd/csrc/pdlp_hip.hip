@@ -72,11 +72,17 @@ template <typename T> __device__ __forceinline__ T block_sum(T v, T* buf)
 // ------------------------------------------------------------------------------------------------
 // epilogues: called once per row with the row's dot product
 // ------------------------------------------------------------------------------------------------
+// Every epilogue also offers pre(row) / operator()(row, sum, pre, acc): the CSR kernel issues the row's operand loads
+// (pre) together with the matrix loads, so they are off the dependent chain product -> epilogue.
+struct NoPre {};
 template <typename T> struct StoreEpi {
     static constexpr int NA = 0;
+    typedef NoPre Pre;
     T* out;
     __device__ void load() {}
+    __device__ Pre pre(int) const { return Pre{}; }
     __device__ void operator()(int i, T s, double*) const { out[i] = s; }
+    __device__ void operator()(int i, T s, const Pre&, double* a) const { (*this)(i, s, a); }
 };
 
 // primal half-step over this rank's rows of K' (= its variables).  kty = (K'y)_j.
@@ -91,22 +97,25 @@ template <typename T, bool ADAPT> struct PrimalEpi {
         theta = (T)sc[S_THETA];
         w = ADAPT ? (T)sc[S_WPEND] : (T)sc[S_ETA];
     }
-    __device__ void operator()(int j, T kty, double* acc) const
+    struct Pre { T xo, cj, lo, hi, sum; };
+    __device__ Pre pre(int j) const { return Pre{x_old[j], c[j], l[j], u[j], x_sum[j]}; }
+    __device__ void operator()(int j, T kty, double* acc) const { (*this)(j, kty, pre(j), acc); }
+    __device__ void operator()(int j, T kty, const Pre& p, double* acc) const
     {
-        const T xo = x_old[j];
-        const T grad = c[j] - kty;
+        const T xo = p.xo;
+        const T grad = p.cj - kty;
         T v = xo - tau * grad;
-        const T lo = l[j], hi = u[j];
+        const T lo = p.lo, hi = p.hi;
         v = v < lo ? lo : v;
         v = v > hi ? hi : v;
         const T d = v - xo;
         x_new[j] = v;
         xbar[j] = v + theta * d;
         if (ADAPT) {
-            x_sum[j] += w * xo;           // weight of the PREVIOUS iterate, known only now
+            x_sum[j] = p.sum + w * xo;    // weight of the PREVIOUS iterate, known only now
             acc[0] += (double)d * (double)d;
         } else {
-            x_sum[j] += w * v;
+            x_sum[j] = p.sum + w * v;
         }
     }
 };
@@ -123,23 +132,26 @@ template <typename T, bool ADAPT> struct DualEpi {
         w = ADAPT ? (T)sc[S_WPEND] : (T)sc[S_ETA];
         inv1pt = (T)sc[S_INV1PT];
     }
-    __device__ void operator()(int i, T kxbar, double* acc) const
+    struct Pre { T yo, qi, sum, kxo; };
+    __device__ Pre pre(int i) const { return Pre{y_old[i], q[i], y_sum[i], ADAPT ? kx[i] : (T)0}; }
+    __device__ void operator()(int i, T kxbar, double* acc) const { (*this)(i, kxbar, pre(i), acc); }
+    __device__ void operator()(int i, T kxbar, const Pre& p, double* acc) const
     {
-        const T yo = y_old[i];
-        T v = yo + sigma * (q[i] - kxbar);
+        const T yo = p.yo;
+        T v = yo + sigma * (p.qi - kxbar);
         if (i < ineq_end && v < (T)0) v = (T)0;
         y_new[i] = v;
         if (ADAPT) {
-            y_sum[i] += w * yo;
+            y_sum[i] = p.sum + w * yo;
             const T dy = v - yo;
             // K dx = (K xbar - K x) / (1 + theta) because xbar = x + (1 + theta) dx; kx caches K x
-            const T kxo = kx[i];
+            const T kxo = p.kxo;
             const T kdx = (kxbar - kxo) * inv1pt;
             kx[i] = kxo + kdx;
             acc[0] += (double)dy * (double)dy;
             acc[1] += (double)dy * (double)kdx;
         } else {
-            y_sum[i] += w * v;
+            y_sum[i] = p.sum + w * v;
         }
     }
 };
@@ -149,12 +161,15 @@ template <typename T, bool UNSCALE> struct KktDualEpi {
     static constexpr int NA = 4;
     const T* x; const T* c; const T* l; const T* u; const T* dcol;
     __device__ void load() {}
-    __device__ void operator()(int j, T kty, double* acc) const
+    struct Pre { T cj, lo, hi, xj, d; };
+    __device__ Pre pre(int j) const { return Pre{c[j], l[j], u[j], x[j], UNSCALE ? dcol[j] : (T)1}; }
+    __device__ void operator()(int j, T kty, double* acc) const { (*this)(j, kty, pre(j), acc); }
+    __device__ void operator()(int j, T kty, const Pre& p, double* acc) const
     {
-        T cj = c[j], lo = l[j], hi = u[j], xj = x[j];
+        T cj = p.cj, lo = p.lo, hi = p.hi, xj = p.xj;
         T g = cj - kty;
         if (UNSCALE) {            // K_u'(D_row y) = (K_s'y)/D_col, c_u = c_s/D_col, l_u = l_s D_col, x_u = D_col x
-            const T d = dcol[j];
+            const T d = p.d;
             g = g / d; cj = cj / d; lo = lo * d; hi = hi * d; xj = xj * d;
         }
         const bool ninf = isinf(lo) && lo < (T)0, pinf = isinf(hi) && hi > (T)0;
@@ -177,13 +192,16 @@ template <typename T, bool UNSCALE> struct KktPrimalEpi {
     static constexpr int NA = 2;
     const T* y; const T* q; const T* drow; T* kx_out; int ineq_end;
     __device__ void load() {}
-    __device__ void operator()(int i, T kx, double* acc) const
+    struct Pre { T qi, yi, d; };
+    __device__ Pre pre(int i) const { return Pre{q[i], y[i], UNSCALE ? drow[i] : (T)1}; }
+    __device__ void operator()(int i, T kx, double* acc) const { (*this)(i, kx, pre(i), acc); }
+    __device__ void operator()(int i, T kx, const Pre& p, double* acc) const
     {
         if (kx_out) kx_out[i] = kx;
-        T qi = q[i], yi = y[i];
+        T qi = p.qi, yi = p.yi;
         T r = kx - qi;
         if (UNSCALE) {            // K_u (D_col x) = (K_s x)/D_row, q_u = q_s/D_row, y_u = D_row y
-            const T d = drow[i];
+            const T d = p.d;
             r = r / d; qi = qi / d; yi = yi * d;
         }
         if (i < ineq_end && r > (T)0) r = (T)0;
@@ -198,7 +216,10 @@ template <typename T, bool UNSCALE> struct KktPrimalEpi {
 template <typename T> struct InfeasDualEpi {
     static constexpr int NA = 4;
     const T* x; const T* x_prev; const T* c; const T* l; const T* u; const T* ktdy; T* lam_prev; T tol;
+    typedef NoPre Pre;
     __device__ void load() {}
+    __device__ Pre pre(int) const { return Pre{}; }
+    __device__ void operator()(int j, T kty, const Pre&, double* acc) const { (*this)(j, kty, acc); }
     __device__ void operator()(int j, T kty, double* acc) const
     {
         const T cj = c[j], lo = l[j], hi = u[j];
@@ -232,7 +253,10 @@ template <typename T> struct InfeasDualEpi {
 template <typename T> struct InfeasPrimalEpi {
     static constexpr int NA = 4;
     const T* y; const T* y_prev; const T* q; T tol; int ineq_end;
+    typedef NoPre Pre;
     __device__ void load() {}
+    __device__ Pre pre(int) const { return Pre{}; }
+    __device__ void operator()(int i, T kdx, const Pre&, double* acc) const { (*this)(i, kdx, acc); }
     __device__ void operator()(int i, T kdx, double* acc) const
     {
         const T dy = y[i] - y_prev[i];                                       // :109
@@ -249,21 +273,16 @@ template <typename T> struct InfeasPrimalEpi {
 // ------------------------------------------------------------------------------------------------
 // the fused CSR kernel
 // ------------------------------------------------------------------------------------------------
+// one workgroup's share of a CSR product: row blocks (and chunks of long rows) first, first + step, ...
+// prod: NNZ_CAP values of LDS, tred: 4 values.  Called by every thread of the workgroup.
 template <typename T, class Epi>
-__global__ __launch_bounds__(BLOCK) void k_csr_fused(const int32_t* __restrict__ blk, int nblk,
-                                                     const int32_t* __restrict__ lch, int nchunks, T* __restrict__ longpart,
-                                                     const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
-                                                     const T* __restrict__ va, const T* __restrict__ vin, Epi epi,
-                                                     double* __restrict__ partials)
+__device__ __forceinline__ void csr_pass(int first, int step, const int32_t* __restrict__ blk, int nblk,
+                                         const int32_t* __restrict__ lch, int nchunks, T* __restrict__ longpart,
+                                         const int32_t* __restrict__ rp, const int32_t* __restrict__ ci, const T* __restrict__ va,
+                                         const T* vin, const Epi& epi, double* acc, T* prod, T* tred)
 {
-    __shared__ T prod[NNZ_CAP];
-    __shared__ T tred[4];
-    __shared__ double dred[4];
     const int tid = threadIdx.x;
-    epi.load();
-    double acc[NACC] = {0.0, 0.0, 0.0, 0.0};
-
-    for (int b = blockIdx.x; b < nblk + nchunks; b += gridDim.x) {
+    for (int b = first; b < nblk + nchunks; b += step) {
         if (b >= nblk) {
             // one NNZ_CAP-sized chunk of a row too long for the LDS staging: its partial sum goes to longpart[chunk];
             // k_long_rows adds a row's chunks in order and runs the epilogue (dense columns of real LPs put
@@ -277,32 +296,63 @@ __global__ __launch_bounds__(BLOCK) void k_csr_fused(const int32_t* __restrict__
             __syncthreads();
             continue;
         }
-        const int r0 = blk[b], r1 = blk[b + 1];
-        const int a = rp[r0], e = rp[r1];
+        // the schedule holds (first row, first non-zero) per block: one load round gives the block's extent
+        const int r0 = blk[2 * b], a = blk[2 * b + 1], r1 = blk[2 * b + 2], e = blk[2 * b + 3];
         const int nn = e - a, nrows = r1 - r0;
         if (nn <= NNZ_CAP) {
-            // stage the products: coalesced value/index reads, gathered vector reads
-#ifdef PDLP_ABL_NOGATHER      /* timing-only build */
-            for (int i = tid; i < nn; i += BLOCK) prod[i] = va[a + i] * (T)(ci[a + i] & 1);
-#else
-            for (int i = tid; i < nn; i += BLOCK) prod[i] = va[a + i] * vin[ci[a + i]];
-#endif
-            __syncthreads();
             // 1..64 lanes per row (a power of two, so a row never straddles a wave)
             int tpr = 1 << (31 - __clz(BLOCK / nrows));
             tpr = tpr > 64 ? 64 : tpr;
             const int lr = tid / tpr, lt = tid & (tpr - 1);
-            T s = (T)0;
-            int row = r0 + lr;
-            if (lr < nrows) {
-                const int p0 = rp[row] - a, p1 = rp[row + 1] - a;
-                for (int p = p0 + lt; p < p1; p += tpr) s += prod[p];
+            const int row = r0 + lr;
+            const bool owner = lr < nrows && lt == 0;
+            // everything that depends only on the block's extent is requested up front: the items, the row's segment
+            // bounds and the epilogue's operands; the only dependent round after this one is the gather
+            constexpr int UNR = NNZ_CAP / BLOCK;
+            T vv[UNR];
+            int cc[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int i = tid + u * BLOCK;
+                if (i < nn) { vv[u] = va[a + i]; cc[u] = ci[a + i]; }
             }
+            int p0 = 0, p1 = 0;
+            if (lr < nrows) { p0 = rp[row] - a; p1 = rp[row + 1] - a; }
+            typename Epi::Pre pre{};
+            if (owner) pre = epi.pre(row);
+#ifdef PDLP_ABL_NOGATHER      /* timing-only build */
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) if (tid + u * BLOCK < nn) vv[u] *= (T)(cc[u] & 1);
+#else
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) if (tid + u * BLOCK < nn) vv[u] *= vin[cc[u]];
+#endif
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) if (tid + u * BLOCK < nn) prod[tid + u * BLOCK] = vv[u];
+            __syncthreads();
+            T s = (T)0;
+            for (int p = p0 + lt; p < p1; p += tpr) s += prod[p];
             for (int off = tpr >> 1; off > 0; off >>= 1) s += shfl_xor_t(s, off);
-            if (lr < nrows && lt == 0) epi(row, s, acc);
+            if (owner) epi(row, s, pre, acc);
             __syncthreads();
         }       // (a single row longer than NNZ_CAP is covered by chunks, see above)
     }
+}
+
+template <typename T, class Epi>
+__global__ __launch_bounds__(BLOCK) void k_csr_fused(const int32_t* __restrict__ blk, int nblk,
+                                                     const int32_t* __restrict__ lch, int nchunks, T* __restrict__ longpart,
+                                                     const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                                                     const T* __restrict__ va, const T* __restrict__ vin, Epi epi,
+                                                     double* __restrict__ partials)
+{
+    __shared__ T prod[NNZ_CAP];
+    __shared__ T tred[4];
+    __shared__ double dred[4];
+    const int tid = threadIdx.x;
+    epi.load();
+    double acc[NACC] = {0.0, 0.0, 0.0, 0.0};
+    csr_pass<T, Epi>(blockIdx.x, gridDim.x, blk, nblk, lch, nchunks, longpart, rp, ci, va, vin, epi, acc, prod, tred);
     if (Epi::NA > 0) {
 #pragma unroll
         for (int r = 0; r < Epi::NA; ++r) {
@@ -312,7 +362,18 @@ __global__ __launch_bounds__(BLOCK) void k_csr_fused(const int32_t* __restrict__
     }
 }
 
-// epilogue of the rows that k_csr_fused handled in chunks: chunk sums added in fixed order
+// epilogue of the rows that csr_pass handled in chunks: chunk sums added in fixed order
+template <typename T, class Epi>
+__device__ __forceinline__ void long_pass(int first, int step, const int32_t* lrow, const int32_t* lptr, int nlong, const T* longpart,
+                                          const Epi& epi, double* acc)
+{
+    for (int i = first; i < nlong; i += step) {
+        T s = (T)0;
+        for (int c = lptr[i]; c < lptr[i + 1]; ++c) s += longpart[c];
+        epi(lrow[i], s, acc);
+    }
+}
+
 template <typename T, class Epi>
 __global__ __launch_bounds__(BLOCK) void k_long_rows(const int32_t* __restrict__ lrow, const int32_t* __restrict__ lptr, int nlong,
                                                      const T* __restrict__ longpart, Epi epi, double* __restrict__ partials)
@@ -320,11 +381,7 @@ __global__ __launch_bounds__(BLOCK) void k_long_rows(const int32_t* __restrict__
     __shared__ double dred[4];
     epi.load();
     double acc[NACC] = {0.0, 0.0, 0.0, 0.0};
-    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nlong; i += gridDim.x * BLOCK) {
-        T s = (T)0;
-        for (int c = lptr[i]; c < lptr[i + 1]; ++c) s += longpart[c];
-        epi(lrow[i], s, acc);
-    }
+    long_pass<T, Epi>(blockIdx.x * BLOCK + threadIdx.x, gridDim.x * BLOCK, lrow, lptr, nlong, longpart, epi, acc);
     if (Epi::NA > 0) {
 #pragma unroll
         for (int r = 0; r < Epi::NA; ++r) {
@@ -846,7 +903,7 @@ __global__ __launch_bounds__(BLOCK) void k_div_cols(int64_t nnz, const int32_t* 
 // host side
 // ------------------------------------------------------------------------------------------------
 struct Schedule {
-    int32_t* blk = nullptr;   // device, nblk+1 row starts
+    int32_t* blk = nullptr;   // device, nblk+1 pairs (first row, first non-zero)
     int nblk = 0;
     int grid = 0;
     // rows longer than NNZ_CAP, cut into chunks of NNZ_CAP non-zeros
@@ -893,10 +950,12 @@ void build_long_rows_host(const std::vector<int32_t>& rp, int64_t rows, std::vec
     }
 }
 
+// out = (first row, first non-zero) of every block, then (rows, nnz) as the end marker: 2 * (blocks + 1) entries
 void build_schedule_host(const std::vector<int32_t>& rp, int64_t rows, std::vector<int32_t>& out)
 {
     out.clear();
     int64_t r = 0;
+    out.push_back(0);
     out.push_back(0);
     while (r < rows) {
         int64_t e = r;
@@ -909,6 +968,7 @@ void build_schedule_host(const std::vector<int32_t>& rp, int64_t rows, std::vect
         }
         if (e == r) e = r + 1;   // a single row longer than NNZ_CAP: its own (skipped) block, done in chunks
         out.push_back((int32_t)e);
+        out.push_back(rp[e]);
         r = e;
     }
 }
@@ -1328,8 +1388,8 @@ int64_t layout(const pdlp_problem* p, int64_t nnzK, int64_t nnzKT, int64_t* offs
     offs[k++] = c.take(pgrid * NACC * 8);                         // 15    partB
     offs[k++] = c.take(PDLP_NRED * 8);                            // 16    red
     offs[k++] = c.take(PDLP_NSCAL * 8);                           // 17    sc
-    offs[k++] = c.take((max_blocks(ml, nnzK) + 1) * 4);           // 18    schedule K
-    offs[k++] = c.take((max_blocks(nl, nnzKT) + 1) * 4);          // 19    schedule K'
+    offs[k++] = c.take((max_blocks(ml, nnzK) + 1) * 8);           // 18    schedule K
+    offs[k++] = c.take((max_blocks(nl, nnzKT) + 1) * 8);          // 19    schedule K'
     offs[k++] = c.take(rowsum_groups(nl > ml ? nl : ml) * ((nl > ml ? nl : ml) + (int64_t)TNT * TRPT_MAX_ANY) * es);   // 20  rowsum scratch
     for (int t = 0; t < 2; ++t) {                                 // 21..28 long rows of K, then of K'
         const int64_t nnz = t == 0 ? nnzK : nnzKT;
@@ -1444,11 +1504,11 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
 
     std::vector<int32_t> sched;
     build_schedule_host(rpK, ml, sched);
-    h->sK.nblk = ml > 0 ? (int)sched.size() - 1 : 0;
+    h->sK.nblk = ml > 0 ? (int)sched.size() / 2 - 1 : 0;
     h->sK.grid = h->sK.nblk < MAX_GRID ? h->sK.nblk : MAX_GRID;
     rc = hipMemcpy(h->sK.blk, sched.data(), sched.size() * 4, hipMemcpyHostToDevice) == hipSuccess ? PDLP_OK : PDLP_ERR_HIP_BASE - 1;
     build_schedule_host(rpKT, nl, sched);
-    h->sKT.nblk = nl > 0 ? (int)sched.size() - 1 : 0;
+    h->sKT.nblk = nl > 0 ? (int)sched.size() / 2 - 1 : 0;
     h->sKT.grid = h->sKT.nblk < MAX_GRID ? h->sKT.nblk : MAX_GRID;
     if (rc == PDLP_OK && hipMemcpy(h->sKT.blk, sched.data(), sched.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
         rc = PDLP_ERR_HIP_BASE - 1;
