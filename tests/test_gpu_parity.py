@@ -830,3 +830,52 @@ def test_infeasibility_detection_off_is_untouched_and_on_counts_passes(golden):
     assert (k1, n1, st1) == (k0, n0, st0) and j1 == j0 + k0 - 1
     assert torch.equal(x0, x1) and obj0 == obj1
 
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE.json's full size (configs[3]/[4], the bench workload): too big for the oracle, so size-independent properties
+# ---------------------------------------------------------------------------------------------------
+def test_full_size_10Mx10M_properties(monkeypatch):
+    """10M x 10M, 1e9 non-zeros, the tiled kernels the benchmark times: linearity of both products, the adjoint identity
+    <K x, y> = <x, K'y> between the two independently built tiled copies, agreement of the tiled and the CSR kernel on the
+    whole matrix, one adaptive PDHG iteration + KKT pass on both kernel families, and the row sums of K against the CSR data"""
+    n = 10_000_000
+    lp = gen_lp(n, n, 100, seed=0, device=DEV)
+    K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
+    assert K.nnz == 1_000_000_000
+    monkeypatch.setenv("PDLP_TILED", "1")
+    e1 = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
+    assert all(t is not None and t.groups == 1 for t in e1.tiles)           # the fused tiled kernel on both matrices
+    g = torch.Generator(device=DEV).manual_seed(2)
+    x1, x2 = torch.randn(n, device=DEV, generator=g), torch.randn(n, device=DEV, generator=g)
+    y1 = torch.randn(n, device=DEV, generator=g)
+    kx1, kx2 = e1.spmv(x1, False), e1.spmv(x2, False)
+    lin = e1.spmv(2.0 * x1 - x2, False) - (2.0 * kx1 - kx2)
+    assert float(lin.abs().max()) <= 2e-5 * float(kx1.abs().max())
+    kty1 = e1.spmv(y1, True)
+    lhs, rhs = float((kx1.double() * y1.double()).sum()), float((x1.double() * kty1.double()).sum())
+    assert abs(lhs - rhs) <= 1e-6 * (float(kx1.double().norm()) * float(y1.double().norm()))
+    ones = torch.ones(n, device=DEV)
+    rows = torch.repeat_interleave(torch.arange(1000, device=DEV), (lp.rowptr[1:1001] - lp.rowptr[:1000]).long())
+    want = torch.zeros(1000, device=DEV, dtype=torch.float64).index_add_(0, rows, lp.val[:int(lp.rowptr[1000])].double())
+    close(e1.spmv(ones, False)[:1000], want.cpu().numpy(), 1e-5)            # K 1 = row sums, straight from the CSR arrays
+    x0 = torch.minimum(torch.maximum(x1, lp.l), lp.u)
+    y0 = y1.clone()
+    y0[:lp.m_ineq].clamp_(min=0)
+    monkeypatch.setenv("PDLP_TILED", "0")
+    e0 = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
+    assert e0.tiles == [None, None]
+    close(e0.spmv(x1, False), kx1.cpu().numpy(), 2e-5)                      # CSR kernel vs tiled kernel, all 1e9 non-zeros
+    close(e0.spmv(y1, True), kty1.cpu().numpy(), 2e-5)
+    outs = []
+    for e in (e0, e1):
+        e.set_iterate(x0, y0)
+        e.set_step(0.02, 1.0, 1.0, 0)
+        e.iterate(2, True)
+        x, y = e.get_iterate(N.CUR)
+        outs.append((x, y, e.scalars()["eta"], e.kkt(N.CUR, 1.0)))
+    a, b = outs
+    close(b[0], a[0].cpu().numpy(), 2e-5)
+    close(b[1], a[1].cpu().numpy(), 2e-5)
+    np.testing.assert_allclose(b[2], a[2], rtol=1e-4)
+    for key in ("pr", "dr", "p", "d_adj", "kkt"):
+        np.testing.assert_allclose(b[3][key], a[3][key], rtol=1e-4)
