@@ -48,7 +48,8 @@ enum {
     PDLP_BUF_X_SUM = 8, PDLP_BUF_Y_SUM = 9,   /* local length: eta-weighted sums (pdhg.py:107-108)         */
     PDLP_BUF_SCALARS = 10,   /* double[PDLP_NSCAL]: eta, omega, theta, tau, sigma, w_pending, eta_sum, k  */
     PDLP_BUF_DX = 11,        /* full length n: x - x_prev of the last step (infeasibility detection)      */
-    PDLP_BUF_DY = 12         /* full length m: y - y_prev                                                 */
+    PDLP_BUF_DY = 12,        /* full length m: y - y_prev                                                 */
+    PDLP_BUF_LAM_PREV = 13   /* local length: the previous lambda of the infeasibility detector (pdhg.py:40,101) */
 };
 #define PDLP_NRED 8
 #define PDLP_NSCAL 16
@@ -227,6 +228,10 @@ int pdlp_csr_div_cols(int dtype, int64_t rows, const int32_t* rowptr, const int3
                       const void* norm_full, void* stream);
 /* elementwise helpers for D /= norm, c*D, l/D ... (:51,:56,:64-67); op: 0 a*=b, 1 a/=b */
 int pdlp_vec_muldiv(int dtype, int64_t len, void* a, const void* b, int op, void* stream);
+/* out = project_lambda_box(g) (helpers.py:3-39): 0 where l = -inf and u = +inf, min(g,0) where only l = -inf,
+ * max(g,0) where only u = +inf, g otherwise.  (Inside the solver this projection is fused into the KKT and
+ * infeasibility epilogues; this entry point serves the reference-named operator.) */
+int pdlp_vec_project_lambda(int dtype, int64_t len, const void* g, const void* l, const void* u, void* out, void* stream);
 /* max_i |1 - v[i]| (the early-exit test :60-61); host result, synchronises */
 int pdlp_vec_max_dev_from_one(int dtype, int64_t len, const void* v, void* work8, double* out, void* stream);
 

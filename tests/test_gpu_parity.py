@@ -170,6 +170,23 @@ def test_reference_named_ops(golden):
     ld[inn], ud[ipn] = 0, 0
     kk2 = tp.KKT_error(col(rk["x"]), col(rk["y"]), c, q, K, int(a["m_ineq"]), dev(rk["omega"]), inn, ipn, ld, ud, DEV)
     assert float(kk2) == float(kk)
+    # the detector's two operators, called the way pdhg.py:90-92 calls them
+    gi = golden("infeasibility.npz")
+    ai, Ki, oi, _ = golden_lp(gi, "op/mixed_400x300")
+    ri = gi.group("op/mixed_400x300/s12")
+    ci_, qi_, li_, ui_ = col(ai["c"]), col(ai["q"]), col(ai["l"]), col(ai["u"])
+    inn, ipn = torch.isinf(li_) & (li_ < 0), torch.isinf(ui_) & (ui_ > 0)
+    grad = ci_ - col(oi.spmv(ri["y"], True))
+    lam = tp.project_lambda_box(grad, inn, ipn)
+    want = grad.clone()
+    want[inn & ipn] = 0
+    want[inn & ~ipn] = want[inn & ~ipn].clamp(max=0)
+    want[ipn & ~inn] = want[ipn & ~inn].clamp(min=0)
+    assert lam.shape == grad.shape and torch.equal(lam, want)
+    for tol, wanted in zip(ri["tols"], ri["status"]):
+        st = tp.detect_infeasibility(col(ri["x"]), col(ri["y"]), col(ri["x_prev"]), col(ri["y_prev"]), lam, col(ri["lam_prev"]),
+                                     ci_, qi_, Ki, li_, ui_, int(ai["m_ineq"]), DEV, tol=float(tol))
+        assert (st or "None") == str(wanted), tol
 
 
 @pytest.mark.parametrize("name", LP_CASES)

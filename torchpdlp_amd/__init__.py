@@ -11,7 +11,8 @@ from .engine import Comm, PdlpEngine                                     # noqa:
 from .solver import (STATUS_KKT_LIMIT, STATUS_SOLVED, STATUS_TIME_LIMIT, check_termination,   # noqa: F401
                      pdlp_algorithm, run_pdlp)
 from .ops import (KKT_error, adaptive_one_step_pdhg, compute_residuals_and_duality_gap,       # noqa: F401
-                  fixed_one_step_pdhg, primal_weight_update, spectral_norm_estimate_torch)
+                  detect_infeasibility, fixed_one_step_pdhg, primal_weight_update, project_lambda_box,
+                  spectral_norm_estimate_torch)
 from .precondition import ruiz_precondition                              # noqa: F401
 from .synthetic import SyntheticLP, gen_lp                               # noqa: F401
 from .mps import mps_to_standard_form, parse_mps                         # noqa: F401

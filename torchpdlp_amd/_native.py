@@ -15,7 +15,7 @@ ABI_VERSION = 3
 PDLP_F32, PDLP_F64 = 0, 1
 CUR, AVG, PREV = 0, 1, 2
 (BUF_X_CUR, BUF_X_PREV, BUF_XBAR, BUF_X_AVG, BUF_Y_CUR, BUF_Y_PREV, BUF_Y_AVG, BUF_RED, BUF_X_SUM, BUF_Y_SUM,
- BUF_SCALARS, BUF_DX, BUF_DY) = range(13)
+ BUF_SCALARS, BUF_DX, BUF_DY, BUF_LAM_PREV) = range(14)
 NRED, NSCAL = 8, 16
 # indices into the scalar block
 S_ETA, S_OMEGA, S_THETA, S_TAU, S_SIGMA, S_WPEND, S_ETASUM, S_K, S_INV1PT, S_ACCEPT, S_ETABAR, S_DEN = range(12)
@@ -80,6 +80,7 @@ SIGNATURES = {
     "pdlp_csr_div_rows": (_I, [_I, _I64, _P, _P, _P, _P]),
     "pdlp_csr_div_cols": (_I, [_I, _I64, _P, _P, _P, _P, _P]),
     "pdlp_vec_muldiv": (_I, [_I, _I64, _P, _P, _I, _P]),
+    "pdlp_vec_project_lambda": (_I, [_I, _I64, _P, _P, _P, _P, _P]),
     "pdlp_vec_max_dev_from_one": (_I, [_I, _I64, _P, _P, C.POINTER(_D), _P]),
 }
 

@@ -791,6 +791,18 @@ __global__ __launch_bounds__(BLOCK) void k_average(int64_t n, T* __restrict__ av
 
 __global__ void k_clear_pending(double* sc) { sc[S_WPEND] = 0.0; }
 
+// lam = project_lambda_box(g) (helpers.py:21-37) with the bound classes read off l, u
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_project_lambda(int64_t n, const T* __restrict__ g, const T* __restrict__ l,
+                                                          const T* __restrict__ u, T* __restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const T lo = l[i], hi = u[i], gi = g[i];
+        const bool ninf = isinf(lo) && lo < (T)0, pinf = isinf(hi) && hi > (T)0;
+        out[i] = (ninf && pinf) ? (T)0 : (ninf ? (gi < (T)0 ? gi : (T)0) : (pinf ? (gi > (T)0 ? gi : (T)0) : gi));
+    }
+}
+
 // out = a - b
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_sub(int64_t n, T* __restrict__ out, const T* __restrict__ a, const T* __restrict__ b)
@@ -1564,6 +1576,7 @@ int pdlp_buffer_ptr(pdlp_handle h, int which, void** ptr)
         case PDLP_BUF_SCALARS: *ptr = h->sc; break;
         case PDLP_BUF_DX: *ptr = h->dxf; break;
         case PDLP_BUF_DY: *ptr = h->dyf; break;
+        case PDLP_BUF_LAM_PREV: *ptr = h->lam_prev; break;
         default: return PDLP_ERR_INVALID;
     }
     return PDLP_OK;
@@ -1976,6 +1989,20 @@ int pdlp_vec_muldiv(int dtype, int64_t len, void* a, const void* b, int op, void
         hipLaunchKernelGGL(k_muldiv<float>, dim3(grid_for(len)), dim3(BLOCK), 0, (hipStream_t)stream, len, (float*)a, (const float*)b, op);
     else
         hipLaunchKernelGGL(k_muldiv<double>, dim3(grid_for(len)), dim3(BLOCK), 0, (hipStream_t)stream, len, (double*)a, (const double*)b, op);
+    HIP_TRY(hipGetLastError());
+    return PDLP_OK;
+}
+
+int pdlp_vec_project_lambda(int dtype, int64_t len, const void* g, const void* l, const void* u, void* out, void* stream)
+{
+    if ((dtype != PDLP_F32 && dtype != PDLP_F64) || len < 0 || (len > 0 && (!g || !l || !u || !out))) return PDLP_ERR_INVALID;
+    if (len == 0) return PDLP_OK;
+    if (dtype == PDLP_F32)
+        hipLaunchKernelGGL(k_project_lambda<float>, dim3(grid_for(len)), dim3(BLOCK), 0, (hipStream_t)stream, len, (const float*)g,
+                           (const float*)l, (const float*)u, (float*)out);
+    else
+        hipLaunchKernelGGL(k_project_lambda<double>, dim3(grid_for(len)), dim3(BLOCK), 0, (hipStream_t)stream, len, (const double*)g,
+                           (const double*)l, (const double*)u, (double*)out);
     HIP_TRY(hipGetLastError());
     return PDLP_OK;
 }

@@ -179,7 +179,7 @@ class PdlpEngine:
                 cnt = N.NRED if which == N.BUF_RED else N.NSCAL
                 v = self.workspace[off:off + cnt * 8].view(torch.float64)
             else:
-                ln = {N.BUF_X_SUM: self.nl, N.BUF_Y_SUM: self.ml, N.BUF_DX: self.n, N.BUF_DY: self.m}.get(
+                ln = {N.BUF_X_SUM: self.nl, N.BUF_Y_SUM: self.ml, N.BUF_DX: self.n, N.BUF_DY: self.m, N.BUF_LAM_PREV: self.nl}.get(
                     which, self.n if which <= N.BUF_X_AVG else self.m)
                 v = self.workspace[off:off + ln * self.dtype.itemsize].view(self.dtype)
             self._views[key] = v

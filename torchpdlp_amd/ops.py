@@ -136,6 +136,34 @@ def primal_weight_update(x_prev, x, y_prev, y, omega, smooth_theta):
     return _scalar_like(omega, float(primal_weight_from_distances(dx2, dy2, float(omega), smooth_theta, t)), as_vec(x).dtype)
 
 
+def project_lambda_box(grad, is_neg_inf, is_pos_inf):
+    """project_lambda_box (helpers.py:3-39): the bound classes come in as the reference's two masks."""
+    dev = _device_of(grad)
+    g = as_vec(grad, device=dev)
+    inf = float("inf")
+    zero = torch.zeros_like(g)
+    l = torch.where(as_vec(is_neg_inf, device=dev).bool(), torch.full_like(g, -inf), zero)     # (storage only: which class)
+    u = torch.where(as_vec(is_pos_inf, device=dev).bool(), torch.full_like(g, inf), zero)
+    out = torch.empty_like(g)
+    lib = N.load()
+    N.check(lib.pdlp_vec_project_lambda(N.PDLP_F32 if g.dtype == torch.float32 else N.PDLP_F64, g.numel(), g.data_ptr(),
+                                        l.data_ptr(), u.data_ptr(), out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+            "pdlp_vec_project_lambda")
+    return out.view_as(grad) if isinstance(grad, torch.Tensor) else _col(out)
+
+
+def detect_infeasibility(x, y, x_prev, y_prev, lam, lam_prev, c, q, K, l, u, m_ineq, device=None, tol=1e-2):
+    """detect_infeasibility (enhancements.py:80-161) -> "DUAL_INFEASIBLE" | "PRIMAL_INFEASIBLE" | None.
+    ``lam`` is what the reference's caller computed as project_lambda_box(c - K.T @ y) (pdhg.py:90); the kernels form it
+    from ``y`` themselves, so the argument is accepted and not read."""
+    eng = _engine(K, c, q, l, u, m_ineq)
+    eng.set_iterate(x, y)
+    eng.buffer(N.BUF_X_PREV).copy_(as_vec(x_prev, eng.n, eng.device, eng.dtype))
+    eng.buffer(N.BUF_Y_PREV).copy_(as_vec(y_prev, eng.m, eng.device, eng.dtype))
+    eng.buffer(N.BUF_LAM_PREV).copy_(as_vec(lam_prev, eng.n, eng.device, eng.dtype))
+    return eng.detect_infeasibility(float(tol))
+
+
 def spectral_norm_estimate_torch(K, num_iters=10, b0=None, seed=None):
     """spectral_norm_estimate_torch (helpers.py:41-51); ``b0``/``seed`` pin the reference's unseeded start vector."""
     dev = _device_of(K if isinstance(K, torch.Tensor) else None)
