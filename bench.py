@@ -135,6 +135,7 @@ def measure_roofline(args, eng, dt, adaptive, world):
     b_primal, _ = algorithmic_bytes(nl, eng.m, nnz_kt, sv, si, adaptive)
     _, b_dual = algorithmic_bytes(eng.n, ml, nnz_k, sv, si, adaptive)
     a = int(adaptive)
+    eng.iterate(1, adaptive)        # (leaves no K'y behind from a restart check: the primal half-step below is the full kernel)
     ms_primal = time_kernel(eng, lambda: N.check(eng.lib.pdlp_primal_half(eng.h, a)), args.kernel_reps)
     # the dual kernel flips the iterate buffers each launch: harmless for timing
     ms_dual = time_kernel(eng, lambda: N.check(eng.lib.pdlp_dual_half(eng.h, a)), args.kernel_reps)

@@ -896,3 +896,46 @@ def test_full_size_10Mx10M_properties(monkeypatch):
     np.testing.assert_allclose(b[2], a[2], rtol=1e-4)
     for key in ("pr", "dr", "p", "d_adj", "kkt"):
         np.testing.assert_allclose(b[3][key], a[3][key], rtol=1e-4)
+
+
+def test_kty_reuse_after_restart_checks_changes_nothing(monkeypatch, golden):
+    """the first primal half-step after a restart check takes K'y from the check's KKT pass (same kernel, same sums):
+    fixed-step solves are bit for bit those of the build that recomputes it, adaptive ones agree to rounding"""
+    g = golden("solve_trace.npz")
+    for name, tiled in (("mixed_400x300", "0"), ("box_200x150", "0")):
+        a, K, o, _ = golden_lp(g, name)
+        r = g.group(f"{name}/fixed_pw")
+        args = (K, int(a["m_ineq"]), dev(a["c"]), dev(a["q"]), dev(a["l"]), dev(a["u"]), DEV)
+        outs = {}
+        for adaptive in (False, True):
+            for reuse in (True, False):
+                if reuse:
+                    monkeypatch.delenv("PDLP_NO_KTY_REUSE", raising=False)
+                else:
+                    monkeypatch.setenv("PDLP_NO_KTY_REUSE", "1")
+                tr = dict(kkt=[], omega=[], restarts=[])
+                outs[(adaptive, reuse)] = tp.pdlp_algorithm(*args, tol=1e-4, verbose=False, primal_update=True, adaptive=adaptive,
+                                                            b0=dev(r["b0"]), trace=tr) + (tr,)
+        x1, obj1, k1, n1, j1, st1, _, tr1 = outs[(False, True)]
+        x0, obj0, k0, n0, j0, st0, _, tr0 = outs[(False, False)]
+        assert (k1, n1, j1, st1) == (k0, n0, j0, st0) and torch.equal(x1, x0) and tr1["kkt"] == tr0["kkt"]
+        xa, obja, ka, na, ja, sta, _, _ = outs[(True, True)]
+        xb, objb, kb, nb, jb, stb, _, _ = outs[(True, False)]
+        assert sta == stb == "Solved" and abs(obja - objb) <= 2e-3 * (1 + abs(objb))
+    # the tiled kernels and a precondition run (the un-scaled pass after a restart keeps the scaled K'y)
+    monkeypatch.delenv("PDLP_NO_KTY_REUSE", raising=False)
+    lp = gen_lp(300_000, 250_000, 3, seed=4, device=DEV, recipe="mixed")
+    res = {}
+    for reuse in (True, False):
+        if reuse:
+            monkeypatch.delenv("PDLP_NO_KTY_REUSE", raising=False)
+        else:
+            monkeypatch.setenv("PDLP_NO_KTY_REUSE", "1")
+        monkeypatch.setenv("PDLP_TILED", "1")
+        res[reuse] = tp.solve_lp((lp.c, tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val), lp.q, lp.m_ineq, lp.l, lp.u), tol=1e-4,
+                                 precondition=True, primal_weight_update=True, adaptive_stepsize=False, seed=0)
+    assert res[True].status == res[False].status == "Solved"
+    assert (res[True].iterations, res[True].restarts, res[True].kkt_passes) == (res[False].iterations, res[False].restarts, res[False].kkt_passes)
+    assert torch.equal(res[True].x, res[False].x)
+    # (fixed steps stop on the reference's SIGNED gap test, quirk Q2, well before the objective has settled)
+    assert abs(res[True].objective - lp.opt_obj) <= 5e-2 * (1 + abs(lp.opt_obj))

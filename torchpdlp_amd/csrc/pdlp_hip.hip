@@ -159,13 +159,14 @@ template <typename T, bool ADAPT> struct DualEpi {
 // KKT, dual side (helpers.py:75-84,94 with project_lambda_box helpers.py:21-37 and pdhg.py:11-17)
 template <typename T, bool UNSCALE> struct KktDualEpi {
     static constexpr int NA = 4;
-    const T* x; const T* c; const T* l; const T* u; const T* dcol;
+    const T* x; const T* c; const T* l; const T* u; const T* dcol; T* kty_out;     // kty_out: keeps K'y for the next primal half-step
     __device__ void load() {}
     struct Pre { T cj, lo, hi, xj, d; };
     __device__ Pre pre(int j) const { return Pre{c[j], l[j], u[j], x[j], UNSCALE ? dcol[j] : (T)1}; }
     __device__ void operator()(int j, T kty, double* acc) const { (*this)(j, kty, pre(j), acc); }
     __device__ void operator()(int j, T kty, const Pre& p, double* acc) const
     {
+        if (kty_out) kty_out[j] = kty;
         T cj = p.cj, lo = p.lo, hi = p.hi, xj = p.xj;
         T g = cj - kty;
         if (UNSCALE) {            // K_u'(D_row y) = (K_s'y)/D_col, c_u = c_s/D_col, l_u = l_s D_col, x_u = D_col x
@@ -1003,6 +1004,9 @@ struct pdlp_solver {
     char *dxf, *dyf;              // infeasibility detection: full-length x - x_prev, y - y_prev (gathered by the caller when sharded)
     char *lam_prev, *ktdy;        //   this rank's block of the previous lambda and of K'dy
     bool kx_valid, cand_valid[2];
+    char* ktyb[2];                // K'y of the candidates, kept by their KKT passes: [0] current, [1] averaged iterate
+    int kty_cur;                  // which of the two belongs to the CURRENT iterate after a restart (-1: see cand_valid[0])
+    bool no_kty_reuse;            // PDLP_NO_KTY_REUSE: timing experiments
     double *partA, *partB, *red, *sc;
     void* rowsum;                 // row sums of the tiled kernel on their way to the epilogue: [groups][rs_stride]
     int64_t rs_stride;            // rows + one row block
@@ -1105,12 +1109,29 @@ inline int grid_of(const Schedule& s, int64_t rows)
 template <typename T> T* xloc(pdlp_handle h, int ix) { return (T*)h->xb[ix] + h->p.col0; }
 template <typename T> T* yloc(pdlp_handle h, int ix) { return (T*)h->yb[ix] + h->p.row0; }
 
+// the primal update from a K'y that a KKT pass at this very iterate left behind: no product, one vector kernel
+template <typename T, class Epi> int primal_from_kty(pdlp_handle h, int src, Epi e)
+{
+    if (h->nl == 0) return PDLP_OK;
+    hipLaunchKernelGGL((k_rowsum_epilogue<T, Epi>), dim3(grid_for(h->nl)), dim3(BLOCK), 0, h->stream, (const T*)h->ktyb[src], 1,
+                       (int64_t)0, (int)h->nl, e, h->partA);
+    HIP_TRY(hipGetLastError());
+    return PDLP_OK;
+}
+
 template <typename T> int primal_half_t(pdlp_handle h, int adaptive)
 {
     const double* sc = h->sc;
+    // K'y of the current iterate may still be there from the restart check (of the current iterate if nothing moved
+    // since, or of the candidate the restart adopted)
+    const int src = (h->no_kty_reuse || h->graph_ok || h->sKT.pending) ? -1 : (h->kty_cur >= 0 ? h->kty_cur : (h->cand_valid[0] ? 0 : -1));
     if (adaptive) {
         PrimalEpi<T, true> e{xloc<T>(h, h->ix_cur), xloc<T>(h, h->ix_prev), (T*)h->xbar + h->p.col0, (const T*)h->p.c,
                              (const T*)h->p.l, (const T*)h->p.u, (T*)h->x_sum, sc};
+        if (src >= 0) {
+            h->last_gridA = h->nl > 0 ? grid_for(h->nl) : 0;
+            return primal_from_kty<T>(h, src, e);
+        }
         h->last_gridA = grid_of(h->sKT, h->nl);
         h->use_split = true;
         const int rc = launch_csr<T>(h, true, h->yb[h->ix_cur], e, h->partA);
@@ -1119,6 +1140,7 @@ template <typename T> int primal_half_t(pdlp_handle h, int adaptive)
     }
     PrimalEpi<T, false> e{xloc<T>(h, h->ix_cur), xloc<T>(h, h->ix_prev), (T*)h->xbar + h->p.col0, (const T*)h->p.c,
                           (const T*)h->p.l, (const T*)h->p.u, (T*)h->x_sum, sc};
+    if (src >= 0) return primal_from_kty<T>(h, src, e);
     h->use_split = true;
     const int rc = launch_csr<T>(h, true, h->yb[h->ix_cur], e, h->partA);
     h->use_split = false; h->sKT.pending = false;
@@ -1156,6 +1178,7 @@ template <typename T> int dual_half_t(pdlp_handle h, int adaptive)
     h->ix_cur = h->ix_prev;
     h->ix_prev = t;
     h->cand_valid[0] = h->cand_valid[1] = false;
+    h->kty_cur = -1;
     return PDLP_OK;
 }
 
@@ -1163,14 +1186,18 @@ template <typename T> int kkt_local_t(pdlp_handle h, int which, int unscaled)
 {
     const int ix = which == PDLP_CUR ? h->ix_cur : (which == PDLP_AVG ? h->ix_avg : h->ix_prev);
     T* kx_out = which == PDLP_CUR ? (T*)h->kxb[1] : (which == PDLP_AVG ? (T*)h->kxb[2] : nullptr);
+    // K'y of a candidate is the product the first primal half-step after the check needs again (same kernel, same
+    // sums): keep it.  (A pass at the current iterate after a restart to the average supersedes that restart's copy.)
+    T* kty_out = which == PDLP_CUR ? (T*)h->ktyb[0] : (which == PDLP_AVG ? (T*)h->ktyb[1] : nullptr);
+    if (which == PDLP_CUR || (which == PDLP_AVG && h->kty_cur == 1)) h->kty_cur = -1;     // (the copy about to be overwritten)
     int rc;
     if (unscaled) {
-        KktDualEpi<T, true> ed{xloc<T>(h, ix), (const T*)h->p.c, (const T*)h->p.l, (const T*)h->p.u, (const T*)h->p.d_col};
+        KktDualEpi<T, true> ed{xloc<T>(h, ix), (const T*)h->p.c, (const T*)h->p.l, (const T*)h->p.u, (const T*)h->p.d_col, kty_out};
         if ((rc = launch_csr<T>(h, true, h->yb[ix], ed, h->partA)) != PDLP_OK) return rc;
         KktPrimalEpi<T, true> ep{yloc<T>(h, ix), (const T*)h->p.q, (const T*)h->p.d_row, kx_out, h->ineq_end};
         if ((rc = launch_csr<T>(h, false, h->xb[ix], ep, h->partB)) != PDLP_OK) return rc;
     } else {
-        KktDualEpi<T, false> ed{xloc<T>(h, ix), (const T*)h->p.c, (const T*)h->p.l, (const T*)h->p.u, nullptr};
+        KktDualEpi<T, false> ed{xloc<T>(h, ix), (const T*)h->p.c, (const T*)h->p.l, (const T*)h->p.u, nullptr, kty_out};
         if ((rc = launch_csr<T>(h, true, h->yb[ix], ed, h->partA)) != PDLP_OK) return rc;
         KktPrimalEpi<T, false> ep{yloc<T>(h, ix), (const T*)h->p.q, nullptr, kx_out, h->ineq_end};
         if ((rc = launch_csr<T>(h, false, h->xb[ix], ep, h->partB)) != PDLP_OK) return rc;
@@ -1414,6 +1441,8 @@ int64_t layout(const pdlp_problem* p, int64_t nnzK, int64_t nnzKT, int64_t* offs
     offs[k++] = c.take(p->m * es);                                // 30    dy
     offs[k++] = c.take(nl * es);                                  // 31    lam_prev
     offs[k++] = c.take(nl * es);                                  // 32    K'dy
+    offs[k++] = c.take(nl * es);                                  // 33    K'y from KKT(current)
+    offs[k++] = c.take(nl * es);                                  // 34    K'y from KKT(average)
     return c.off;
 }
 
@@ -1494,6 +1523,9 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     h->sK.blk = (int32_t*)(w + offs[18]); h->sKT.blk = (int32_t*)(w + offs[19]);
     h->rowsum = (void*)(w + offs[20]);
     h->dxf = w + offs[29]; h->dyf = w + offs[30]; h->lam_prev = w + offs[31]; h->ktdy = w + offs[32];
+    h->ktyb[0] = w + offs[33]; h->ktyb[1] = w + offs[34];
+    h->kty_cur = -1;
+    h->no_kty_reuse = std::getenv("PDLP_NO_KTY_REUSE") != nullptr;
     h->rs_stride = (nl > ml ? nl : ml) + (int64_t)TNT * TRPT_MAX_ANY;
     h->rs_groups = (int)rowsum_groups(nl > ml ? nl : ml);
     h->kx_valid = false; h->cand_valid[0] = h->cand_valid[1] = false;
@@ -1618,6 +1650,7 @@ int pdlp_set_iterate(pdlp_handle h, const void* x_local, const void* y_local)
     HIP_TRY(hipGetLastError());
     h->kx_valid = false;
     h->cand_valid[0] = h->cand_valid[1] = false;
+    h->kty_cur = -1;
     return PDLP_OK;
 }
 
@@ -1862,13 +1895,15 @@ int pdlp_restart(pdlp_handle h, int which)
         h->ix_cur = h->ix_avg;
         h->ix_avg = t;
     }
-    if (h->cand_valid[cand]) {     // K x of the chosen point was produced by its KKT pass
+    if (h->cand_valid[cand]) {     // K x and K'y of the chosen point were produced by its KKT pass
         char* t = h->kxb[0];
         h->kxb[0] = h->kxb[1 + cand];
         h->kxb[1 + cand] = t;
         h->kx_valid = true;
+        h->kty_cur = cand;
     } else {
         h->kx_valid = false;
+        if (which == PDLP_AVG) h->kty_cur = -1;
     }
     h->cand_valid[0] = h->cand_valid[1] = false;
     HIP_TRY(hipMemsetAsync(h->x_sum, 0, h->nl * h->es, h->stream));          // pdhg.py:58-60
