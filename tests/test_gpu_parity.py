@@ -939,3 +939,75 @@ def test_kty_reuse_after_restart_checks_changes_nothing(monkeypatch, golden):
     assert torch.equal(res[True].x, res[False].x)
     # (fixed steps stop on the reference's SIGNED gap test, quirk Q2, well before the objective has settled)
     assert abs(res[True].objective - lp.opt_obj) <= 5e-2 * (1 + abs(lp.opt_obj))
+
+
+def test_random_lps_engine_vs_oracle():
+    """a seeded sweep over LP shapes the fixtures do not hold (sizes, densities, row-length laws, bound classes, inequality
+    share, precision, kernel family): a few fixed and adaptive iterations, the running average, a KKT pass and the
+    infeasibility detector's eight sums, HIP path against the oracle"""
+    from torchpdlp_amd.tiled import build_tiles
+    rng = np.random.default_rng(2024)
+    tiled_cases = 0
+    for case in range(18):
+        m, n = int(rng.integers(1, 3000)), int(rng.integers(1, 3000))
+        law = case % 3
+        lens = rng.integers(0, 7, m) if law == 0 else ((rng.pareto(1.3, m) * 2).astype(np.int64).clip(0, n) if law == 1
+                                                      else np.where(rng.random(m) < 0.1, rng.integers(0, min(n, 300) + 1, m), 1))
+        lens = np.minimum(lens, n)
+        rp, ci, va = _random_csr(m, n, lens, 500 + case)
+        m_ineq = int(rng.integers(0, m + 1))
+        dt, npd = (torch.float64, np.float64) if case % 4 == 3 else (torch.float32, np.float32)
+        c, q = rng.standard_normal(n), rng.standard_normal(m)
+        l, u = -rng.random(n) * 3, rng.random(n) * 3
+        cls = rng.integers(0, 5, n)
+        l[cls == 1] = -np.inf
+        u[cls == 2] = np.inf
+        l[cls == 3], u[cls == 3] = -np.inf, np.inf
+        u[cls == 4] = l[cls == 4]
+        o = orc.OracleLP(m, n, m_ineq, rp, ci, va.astype(npd), c, q, l, u, dtype=npd)
+        K = tp.CsrPair(m, n, dev(rp, torch.int32), dev(ci, torch.int32), dev(va, dt))
+        eng = tp.PdlpEngine.from_full(K, dev(c, dt), dev(q, dt), dev(l, dt), dev(u, dt), m_ineq)
+        if case % 2 and m >= 64 and n >= 64:
+            ts = [build_tiles(rp_, ci_, va_, rows, cols, lw=int(rng.integers(6, 10)))
+                  for (rp_, ci_, va_), rows, cols in ((eng.K, m, n), (eng.KT, n, m))]
+            if all(t is not None for t in ts):
+                eng.attach_tiles(0, ts[0])
+                eng.attach_tiles(1, ts[1])
+                tiled_cases += 1
+        x0 = np.clip(rng.standard_normal(n), np.where(np.isinf(l), -2, l), np.where(np.isinf(u), 2, u)).astype(npd)
+        y0 = rng.standard_normal(m).astype(npd)
+        y0[:m_ineq] = np.abs(y0[:m_ineq])
+        tol = 1e-11 if dt == torch.float64 else 5e-5
+        eta0, om = 0.5 / (1.0 + float(np.abs(va).sum()) ** 0.5), 0.9
+        for adaptive in (False, True):
+            eng.set_iterate(dev(x0, dt), dev(y0, dt))
+            eng.set_step(eta0, om, 1.0, 0)
+            eng.infeas_reset()
+            eng.iterate(4, adaptive)
+            xo, yo, e = x0, y0, npd(eta0)
+            xs, ys, es = np.zeros_like(x0), np.zeros_like(y0), npd(0)
+            for k in range(1, 5):
+                xp, yp = xo, yo
+                if adaptive:
+                    xo, yo, w, e, _ = o.step_adaptive(xo, yo, e, om, 1.0, k)
+                else:
+                    xo, yo = o.step_fixed(xo, yo, e, om, 1.0)
+                    w = e
+                xs, ys, es = xs + w * xo, ys + w * yo, npd(es + w)
+            x, y = eng.get_iterate(N.CUR)
+            msg = f"case {case}: {m}x{n} m_ineq={m_ineq} {dt} adaptive={adaptive} tiles={[t is not None for t in eng.tiles]}"
+            np.testing.assert_allclose(x.cpu().numpy(), xo, rtol=tol, atol=tol * (1 + np.abs(xo).max()), err_msg=msg)
+            np.testing.assert_allclose(y.cpu().numpy(), yo, rtol=tol, atol=tol * (1 + np.abs(yo).max()), err_msg=msg)
+            st, diag = eng.detect_infeasibility(1e-3, diagnostics=True)
+            so, _, dgo = o.detect_infeasibility(xo, yo, xp, yp, np.zeros(n, npd), 1e-3)
+            np.testing.assert_allclose(diag, dgo, rtol=20 * tol, atol=20 * tol * (1 + np.abs(dgo).max()), err_msg=msg)
+            if adaptive:
+                eng.flush_average()
+            eng.compute_average()
+            xa, ya = eng.get_iterate(N.AVG)
+            np.testing.assert_allclose(xa.cpu().numpy(), xs / es, rtol=4 * tol, atol=4 * tol * (1 + np.abs(xo).max()), err_msg=msg)
+            got, ref = eng.kkt(N.CUR, om), o.kkt(xo, yo, om)
+            scale = 1 + abs(float(ref["p"])) + abs(float(ref["d_adj"])) + float(ref["pr"]) + float(ref["dr"])
+            for key in ("pr", "dr", "gap", "p", "d_adj", "kkt"):
+                assert abs(got[key] - float(ref[key])) <= 20 * tol * scale, (msg, key, got[key], ref[key])
+    assert tiled_cases >= 3
