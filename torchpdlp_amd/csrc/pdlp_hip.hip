@@ -69,848 +69,10 @@ template <typename T> __device__ __forceinline__ T block_sum(T v, T* buf)
     return buf[0] + buf[1] + buf[2] + buf[3];
 }
 
-// ------------------------------------------------------------------------------------------------
-// epilogues: called once per row with the row's dot product
-// ------------------------------------------------------------------------------------------------
-// Every epilogue also offers pre(row) / operator()(row, sum, pre, acc): the CSR kernel issues the row's operand loads
-// (pre) together with the matrix loads, so they are off the dependent chain product -> epilogue.
-struct NoPre {};
-template <typename T> struct StoreEpi {
-    static constexpr int NA = 0;
-    typedef NoPre Pre;
-    T* out;
-    __device__ void load() {}
-    __device__ Pre pre(int) const { return Pre{}; }
-    __device__ void operator()(int i, T s, double*) const { out[i] = s; }
-    __device__ void operator()(int i, T s, const Pre&, double* a) const { (*this)(i, s, a); }
-};
-
-// primal half-step over this rank's rows of K' (= its variables).  kty = (K'y)_j.
-// step.py:25-30 (fixed) / :74-82 (adaptive); running sum pdhg.py:107.
-template <typename T, bool ADAPT> struct PrimalEpi {
-    static constexpr int NA = ADAPT ? 1 : 0;
-    const T* x_old; T* x_new; T* xbar; const T* c; const T* l; const T* u; T* x_sum; const double* sc;
-    T tau = 0, theta = 0, w = 0;
-    __device__ void load()
-    {
-        tau = (T)sc[S_TAU];
-        theta = (T)sc[S_THETA];
-        w = ADAPT ? (T)sc[S_WPEND] : (T)sc[S_ETA];
-    }
-    struct Pre { T xo, cj, lo, hi, sum; };
-    __device__ Pre pre(int j) const { return Pre{x_old[j], c[j], l[j], u[j], x_sum[j]}; }
-    __device__ void operator()(int j, T kty, double* acc) const { (*this)(j, kty, pre(j), acc); }
-    __device__ void operator()(int j, T kty, const Pre& p, double* acc) const
-    {
-        const T xo = p.xo;
-        const T grad = p.cj - kty;
-        T v = xo - tau * grad;
-        const T lo = p.lo, hi = p.hi;
-        v = v < lo ? lo : v;
-        v = v > hi ? hi : v;
-        const T d = v - xo;
-        x_new[j] = v;
-        xbar[j] = v + theta * d;
-        if (ADAPT) {
-            x_sum[j] = p.sum + w * xo;    // weight of the PREVIOUS iterate, known only now
-            acc[0] += (double)d * (double)d;
-        } else {
-            x_sum[j] = p.sum + w * v;
-        }
-    }
-};
-
-// dual half-step over this rank's rows of K (= its constraints).  kxbar = (K xbar)_i.
-// step.py:33-38 / :85-96; running sum pdhg.py:108.
-template <typename T, bool ADAPT> struct DualEpi {
-    static constexpr int NA = ADAPT ? 2 : 0;
-    const T* y_old; T* y_new; const T* q; T* y_sum; T* kx; const double* sc; int ineq_end;
-    T sigma = 0, w = 0, inv1pt = 0;
-    __device__ void load()
-    {
-        sigma = (T)sc[S_SIGMA];
-        w = ADAPT ? (T)sc[S_WPEND] : (T)sc[S_ETA];
-        inv1pt = (T)sc[S_INV1PT];
-    }
-    struct Pre { T yo, qi, sum, kxo; };
-    __device__ Pre pre(int i) const { return Pre{y_old[i], q[i], y_sum[i], ADAPT ? kx[i] : (T)0}; }
-    __device__ void operator()(int i, T kxbar, double* acc) const { (*this)(i, kxbar, pre(i), acc); }
-    __device__ void operator()(int i, T kxbar, const Pre& p, double* acc) const
-    {
-        const T yo = p.yo;
-        T v = yo + sigma * (p.qi - kxbar);
-        if (i < ineq_end && v < (T)0) v = (T)0;
-        y_new[i] = v;
-        if (ADAPT) {
-            y_sum[i] = p.sum + w * yo;
-            const T dy = v - yo;
-            // K dx = (K xbar - K x) / (1 + theta) because xbar = x + (1 + theta) dx; kx caches K x
-            const T kxo = p.kxo;
-            const T kdx = (kxbar - kxo) * inv1pt;
-            kx[i] = kxo + kdx;
-            acc[0] += (double)dy * (double)dy;
-            acc[1] += (double)dy * (double)kdx;
-        } else {
-            y_sum[i] = p.sum + w * v;
-        }
-    }
-};
-
-// KKT, dual side (helpers.py:75-84,94 with project_lambda_box helpers.py:21-37 and pdhg.py:11-17)
-template <typename T, bool UNSCALE> struct KktDualEpi {
-    static constexpr int NA = 4;
-    const T* x; const T* c; const T* l; const T* u; const T* dcol; T* kty_out;     // kty_out: keeps K'y for the next primal half-step
-    __device__ void load() {}
-    struct Pre { T cj, lo, hi, xj, d; };
-    __device__ Pre pre(int j) const { return Pre{c[j], l[j], u[j], x[j], UNSCALE ? dcol[j] : (T)1}; }
-    __device__ void operator()(int j, T kty, double* acc) const { (*this)(j, kty, pre(j), acc); }
-    __device__ void operator()(int j, T kty, const Pre& p, double* acc) const
-    {
-        if (kty_out) kty_out[j] = kty;
-        T cj = p.cj, lo = p.lo, hi = p.hi, xj = p.xj;
-        T g = cj - kty;
-        if (UNSCALE) {            // K_u'(D_row y) = (K_s'y)/D_col, c_u = c_s/D_col, l_u = l_s D_col, x_u = D_col x
-            const T d = p.d;
-            g = g / d; cj = cj / d; lo = lo * d; hi = hi * d; xj = xj * d;
-        }
-        const bool ninf = isinf(lo) && lo < (T)0, pinf = isinf(hi) && hi > (T)0;
-        T lam;
-        if (ninf && pinf) lam = (T)0;
-        else if (ninf) lam = g < (T)0 ? g : (T)0;
-        else if (pinf) lam = g > (T)0 ? g : (T)0;
-        else lam = g;
-        const T ld = ninf ? (T)0 : lo, ud = pinf ? (T)0 : hi;
-        const T r = g - lam;
-        acc[0] += (double)r * (double)r;
-        acc[1] += (double)ld * (double)(lam > (T)0 ? lam : (T)0);
-        acc[2] += (double)ud * (double)(lam < (T)0 ? lam : (T)0);
-        acc[3] += (double)cj * (double)xj;
-    }
-};
-
-// KKT, primal side (helpers.py:77,87-91).  Optionally keeps K x for the adaptive step's cache.
-template <typename T, bool UNSCALE> struct KktPrimalEpi {
-    static constexpr int NA = 2;
-    const T* y; const T* q; const T* drow; T* kx_out; int ineq_end;
-    __device__ void load() {}
-    struct Pre { T qi, yi, d; };
-    __device__ Pre pre(int i) const { return Pre{q[i], y[i], UNSCALE ? drow[i] : (T)1}; }
-    __device__ void operator()(int i, T kx, double* acc) const { (*this)(i, kx, pre(i), acc); }
-    __device__ void operator()(int i, T kx, const Pre& p, double* acc) const
-    {
-        if (kx_out) kx_out[i] = kx;
-        T qi = p.qi, yi = p.yi;
-        T r = kx - qi;
-        if (UNSCALE) {            // K_u (D_col x) = (K_s x)/D_row, q_u = q_s/D_row, y_u = D_row y
-            const T d = p.d;
-            r = r / d; qi = qi / d; yi = yi * d;
-        }
-        if (i < ineq_end && r > (T)0) r = (T)0;
-        acc[0] += (double)r * (double)r;
-        acc[1] += (double)qi * (double)yi;
-    }
-};
-
-// infeasibility detection (opt-in), variable side -- detect_infeasibility enhancements.py:108-114,124-139,146-157 for
-// the step just taken, with lam = project_lambda_box(c - K'y) (pdhg.py:90, helpers.py:21-37).  Rows of K'.
-// partial sums: ||K'dy - dlam||^2, l_f'dlam_minus + u_f'dlam_plus, c'dx, #{variables failing the bound test}
-template <typename T> struct InfeasDualEpi {
-    static constexpr int NA = 4;
-    const T* x; const T* x_prev; const T* c; const T* l; const T* u; const T* ktdy; T* lam_prev; T tol;
-    typedef NoPre Pre;
-    __device__ void load() {}
-    __device__ Pre pre(int) const { return Pre{}; }
-    __device__ void operator()(int j, T kty, const Pre&, double* acc) const { (*this)(j, kty, acc); }
-    __device__ void operator()(int j, T kty, double* acc) const
-    {
-        const T cj = c[j], lo = l[j], hi = u[j];
-        const T g = cj - kty;
-        const bool ninf = isinf(lo) && lo < (T)0, pinf = isinf(hi) && hi > (T)0;
-        T lam;
-        if (ninf && pinf) lam = (T)0;
-        else if (ninf) lam = g < (T)0 ? g : (T)0;
-        else if (pinf) lam = g > (T)0 ? g : (T)0;
-        else lam = g;
-        const T dlam = lam - lam_prev[j];                                    // :110
-        lam_prev[j] = lam;                                                   // pdhg.py:101
-        const T r = ktdy[j] - dlam;                                          // :146
-        acc[0] += (double)r * (double)r;
-        const T plus = -dlam > (T)0 ? -dlam : (T)0, minus = dlam > (T)0 ? dlam : (T)0;   // :113-114
-        double lu = 0.0;
-        if (!isinf(lo) && lo != (T)0) lu += (double)lo * (double)minus;      // :151,155
-        if (!isinf(hi) && hi != (T)0) lu += (double)hi * (double)plus;       // :152,157
-        acc[1] += lu;
-        const T d = x[j] - x_prev[j];                                        // :108
-        acc[2] += (double)cj * (double)d;                                    // :124
-        const T ad = d < (T)0 ? -d : d;
-        const bool ok = (!isinf(lo) && !isinf(hi) && ad <= tol) || (pinf && cj >= (T)0 && d >= -tol) ||
-                        (ninf && cj <= (T)0 && d <= tol);                    // :135-137
-        acc[3] += ok ? 0.0 : 1.0;
-    }
-};
-
-// infeasibility detection, constraint side (rows of K): kdx = (K dx)_i.  enhancements.py:118,121,148-149
-// partial sums: ||K_eq dx||^2, #{(K_in dx)_i < -tol}, #{dy_i < -tol, i inequality}, q'dy
-template <typename T> struct InfeasPrimalEpi {
-    static constexpr int NA = 4;
-    const T* y; const T* y_prev; const T* q; T tol; int ineq_end;
-    typedef NoPre Pre;
-    __device__ void load() {}
-    __device__ Pre pre(int) const { return Pre{}; }
-    __device__ void operator()(int i, T kdx, const Pre&, double* acc) const { (*this)(i, kdx, acc); }
-    __device__ void operator()(int i, T kdx, double* acc) const
-    {
-        const T dy = y[i] - y_prev[i];                                       // :109
-        if (i < ineq_end) {
-            acc[1] += (kdx >= -tol) ? 0.0 : 1.0;
-            acc[2] += (dy >= -tol) ? 0.0 : 1.0;
-        } else {
-            acc[0] += (double)kdx * (double)kdx;
-        }
-        acc[3] += (double)q[i] * (double)dy;
-    }
-};
-
-// ------------------------------------------------------------------------------------------------
-// the fused CSR kernel
-// ------------------------------------------------------------------------------------------------
-// one workgroup's share of a CSR product: row blocks (and chunks of long rows) first, first + step, ...
-// prod: NNZ_CAP values of LDS, tred: 4 values.  Called by every thread of the workgroup.
-template <typename T, class Epi>
-__device__ __forceinline__ void csr_pass(int first, int step, const int32_t* __restrict__ blk, int nblk,
-                                         const int32_t* __restrict__ lch, int nchunks, T* __restrict__ longpart,
-                                         const int32_t* __restrict__ rp, const int32_t* __restrict__ ci, const T* __restrict__ va,
-                                         const T* vin, const Epi& epi, double* acc, T* prod, T* tred)
-{
-    const int tid = threadIdx.x;
-    for (int b = first; b < nblk + nchunks; b += step) {
-        if (b >= nblk) {
-            // one NNZ_CAP-sized chunk of a row too long for the LDS staging: its partial sum goes to longpart[chunk];
-            // k_long_rows adds a row's chunks in order and runs the epilogue (dense columns of real LPs put
-            // 1e5+ entries into single rows of K' -- one workgroup per row would serialise the whole product)
-            const int c = b - nblk;
-            const int a = lch[2 * c], e = lch[2 * c + 1];
-            T s = (T)0;
-            for (int i = a + tid; i < e; i += BLOCK) s += va[i] * vin[ci[i]];
-            s = block_sum(s, tred);
-            if (tid == 0) longpart[c] = s;
-            __syncthreads();
-            continue;
-        }
-        // the schedule holds (first row, first non-zero) per block: one load round gives the block's extent
-        const int r0 = blk[2 * b], a = blk[2 * b + 1], r1 = blk[2 * b + 2], e = blk[2 * b + 3];
-        const int nn = e - a, nrows = r1 - r0;
-        if (nn <= NNZ_CAP) {
-            // 1..64 lanes per row (a power of two, so a row never straddles a wave)
-            int tpr = 1 << (31 - __clz(BLOCK / nrows));
-            tpr = tpr > 64 ? 64 : tpr;
-            const int lr = tid / tpr, lt = tid & (tpr - 1);
-            const int row = r0 + lr;
-            const bool owner = lr < nrows && lt == 0;
-            // everything that depends only on the block's extent is requested up front: the items, the row's segment
-            // bounds and the epilogue's operands; the only dependent round after this one is the gather
-            constexpr int UNR = NNZ_CAP / BLOCK;
-            T vv[UNR];
-            int cc[UNR];
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int i = tid + u * BLOCK;
-                if (i < nn) { vv[u] = va[a + i]; cc[u] = ci[a + i]; }
-            }
-            int p0 = 0, p1 = 0;
-            if (lr < nrows) { p0 = rp[row] - a; p1 = rp[row + 1] - a; }
-            typename Epi::Pre pre{};
-            if (owner) pre = epi.pre(row);
-#ifdef PDLP_ABL_NOGATHER      /* timing-only build */
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) if (tid + u * BLOCK < nn) vv[u] *= (T)(cc[u] & 1);
-#else
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) if (tid + u * BLOCK < nn) vv[u] *= vin[cc[u]];
-#endif
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) if (tid + u * BLOCK < nn) prod[tid + u * BLOCK] = vv[u];
-            __syncthreads();
-            T s = (T)0;
-            for (int p = p0 + lt; p < p1; p += tpr) s += prod[p];
-            for (int off = tpr >> 1; off > 0; off >>= 1) s += shfl_xor_t(s, off);
-            if (owner) epi(row, s, pre, acc);
-            __syncthreads();
-        }       // (a single row longer than NNZ_CAP is covered by chunks, see above)
-    }
-}
-
-template <typename T, class Epi>
-__global__ __launch_bounds__(BLOCK) void k_csr_fused(const int32_t* __restrict__ blk, int nblk,
-                                                     const int32_t* __restrict__ lch, int nchunks, T* __restrict__ longpart,
-                                                     const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
-                                                     const T* __restrict__ va, const T* __restrict__ vin, Epi epi,
-                                                     double* __restrict__ partials)
-{
-    __shared__ T prod[NNZ_CAP];
-    __shared__ T tred[4];
-    __shared__ double dred[4];
-    const int tid = threadIdx.x;
-    epi.load();
-    double acc[NACC] = {0.0, 0.0, 0.0, 0.0};
-    csr_pass<T, Epi>(blockIdx.x, gridDim.x, blk, nblk, lch, nchunks, longpart, rp, ci, va, vin, epi, acc, prod, tred);
-    if (Epi::NA > 0) {
-#pragma unroll
-        for (int r = 0; r < Epi::NA; ++r) {
-            const double v = block_sum(acc[r], dred);
-            if (tid == 0) partials[(size_t)blockIdx.x * NACC + r] = v;
-        }
-    }
-}
-
-// epilogue of the rows that csr_pass handled in chunks: chunk sums added in fixed order
-template <typename T, class Epi>
-__device__ __forceinline__ void long_pass(int first, int step, const int32_t* lrow, const int32_t* lptr, int nlong, const T* longpart,
-                                          const Epi& epi, double* acc)
-{
-    for (int i = first; i < nlong; i += step) {
-        T s = (T)0;
-        for (int c = lptr[i]; c < lptr[i + 1]; ++c) s += longpart[c];
-        epi(lrow[i], s, acc);
-    }
-}
-
-template <typename T, class Epi>
-__global__ __launch_bounds__(BLOCK) void k_long_rows(const int32_t* __restrict__ lrow, const int32_t* __restrict__ lptr, int nlong,
-                                                     const T* __restrict__ longpart, Epi epi, double* __restrict__ partials)
-{
-    __shared__ double dred[4];
-    epi.load();
-    double acc[NACC] = {0.0, 0.0, 0.0, 0.0};
-    long_pass<T, Epi>(blockIdx.x * BLOCK + threadIdx.x, gridDim.x * BLOCK, lrow, lptr, nlong, longpart, epi, acc);
-    if (Epi::NA > 0) {
-#pragma unroll
-        for (int r = 0; r < Epi::NA; ++r) {
-            const double v = block_sum(acc[r], dred);
-            if (threadIdx.x == 0) partials[(size_t)blockIdx.x * NACC + r] = v;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// the panel-tiled kernel (format: torchpdlp_amd/tiled.py; float32 only).  A workgroup of 512 threads owns
-// 512*rpt rows and walks the column panels in order; two workgroups share a CU (64 KB of LDS each) and all
-// workgroups keep the same pace, so the 256 KB panel of the gathered vector stays in every XCD's L2.  Per tile:
-//   pass 1  items are stored sorted by column (interleaved so that one gather instruction covers 64 consecutive
-//           sorted items, i.e. few 128-byte lines): 16-byte streaming loads of (packed index, value) into
-//           registers one group (8192 items) ahead, gathers, product stored to lds[slot] (slot = the item's rank
-//           in row order: a transposition through LDS with plain stores, no atomics);
-//   pass 2  every thread owns rpt consecutive rows: their 4-bit segment lengths, a workgroup scan gives its
-//           first slot, and it sums its segments into register accumulators.  While one workgroup of the CU
-//           is in pass 2 the other one streams and gathers.
-// After the last panel the row sums go through LDS once more so that the epilogue runs with consecutive lanes
-// on consecutive rows (coalesced vector traffic).
-// ------------------------------------------------------------------------------------------------
-constexpr int TNT = 512;                 // threads per workgroup
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-// per precision: most rows per thread (a multiple of 8: one 32-bit word holds 8 counts), most items per tile
-// (64 KB of LDS products, two workgroups per CU), 4-item chunks per thread and register group
-template <typename T> struct TileCfg;
-template <> struct TileCfg<float> { static constexpr int RPT_MAX = 40, CAP = 16384, TU = 3; typedef f32x4 V4; };
-template <> struct TileCfg<double> { static constexpr int RPT_MAX = 24, CAP = 8192, TU = 2; typedef f64x4 V4; };
-constexpr int TRPT_MAX_ANY = 40;
-
-// FUSED: the workgroup walks ALL panels of its row block and runs the epilogue itself.  Otherwise the panels of
-// a row block are split over `groups` workgroups (blockIdx = group * nblk + row block; needed when there are too
-// few rows for one workgroup per row block to fill the chip, e.g. one rank's shard of a sharded problem): each
-// writes its partial row sums to rowsum[group] and k_rowsum_epilogue adds them in fixed order.
-template <typename T, class Epi, bool FUSED>
-__global__ __launch_bounds__(TNT, 4) void k_tiled_fused(const uint32_t* __restrict__ tidx, const T* __restrict__ tval,
-                                                        const int32_t* __restrict__ tile_ptr, const uint32_t* __restrict__ tcnt,
-                                                        int npanel, int lw, int rpt, int nrows, int nblk, int ppg,
-                                                        int vtotal, int skip_lo, int skip_len, int slot0,
-                                                        const T* __restrict__ vin, T* __restrict__ rowsum,
-                                                        int64_t rs_stride, Epi epi, double* __restrict__ partials)
-{
-    constexpr int TRPT_MAX = TileCfg<T>::RPT_MAX, TCW = TRPT_MAX / 8, TCAP = TileCfg<T>::CAP, TU = TileCfg<T>::TU;
-    constexpr int TGRP = TNT * 4 * TU;       // items per register group
-    typedef typename TileCfg<T>::V4 V4;
-    __shared__ __attribute__((aligned(16))) T prod[TCAP + 8];
-    __shared__ int wsum[TNT / 64];
-    __shared__ double dred8[TNT / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int b = FUSED ? blockIdx.x : blockIdx.x % nblk;
-    const int grp = FUSED ? 0 : blockIdx.x / nblk;
-    // A launch walks `vtotal` panels in "virtual" order: panel = v below skip_lo, v + skip_len from there on.  That
-    // lets one launch cover just the panels of the locally owned block of the gathered vector and another one all the
-    // others (sharded problems: the first runs while the all-gather of the vector is still in flight).
-    const int p_lo = grp * ppg, p_hi = (p_lo + ppg < vtotal) ? p_lo + ppg : vtotal;
-    auto pmap = [&](int v) { return v < skip_lo ? v : v + skip_len; };
-    const uint32_t mask = (1u << lw) - 1u;
-    if (FUSED) epi.load();
-    T acc[TRPT_MAX];
-#pragma unroll
-    for (int r = 0; r < TRPT_MAX; ++r) acc[r] = (T)0;
-
-    const uint32_t trash = (uint32_t)TCAP << lw;       // slot TCAP (past every real slot), column 0
-    // the item stream is read once: non-temporal loads keep it from evicting the gathered panel out of the L2
-    auto load_into = [&](u32x4 (&pk)[TU], V4 (&vv)[TU], int g0, int i1) {
-#pragma unroll
-        for (int u = 0; u < TU; ++u) {
-            const int i = g0 + (u * TNT + tid) * 4;
-            if (i < i1) {
-#ifdef PDLP_TEMPORAL_STREAM
-                pk[u] = *reinterpret_cast<const u32x4*>(tidx + i);
-                vv[u] = *reinterpret_cast<const V4*>(tval + i);
-#else
-                pk[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(tidx + i));
-                vv[u] = __builtin_nontemporal_load(reinterpret_cast<const V4*>(tval + i));
-#endif
-            } else {
-                pk[u] = u32x4{trash, trash, trash, trash};
-                vv[u] = V4{(T)0, (T)0, (T)0, (T)0};
-            }
-        }
-    };
-    // one register group: gathers, then the products go to their row-order slots in LDS.  Chunks of the group that
-    // lie past the tile's end for this whole wave are skipped (wave-uniform).
-    auto consume = [&](u32x4 (&pk)[TU], V4 (&vv)[TU], int g0, int i1, const T* __restrict__ xin) {
-        T xg[TU * 4];
-        bool on[TU];
-#pragma unroll
-        for (int u = 0; u < TU; ++u) on[u] = g0 + (u * TNT + __builtin_amdgcn_readfirstlane(wv) * 64) * 4 < i1;
-#pragma unroll
-        for (int u = 0; u < TU; ++u) if (on[u]) {
-#ifdef PDLP_ABL_NOGATHER
-            xg[4 * u + 0] = xg[4 * u + 1] = xg[4 * u + 2] = xg[4 * u + 3] = (T)(pk[u].x & 1u);
-#else
-            xg[4 * u + 0] = xin[pk[u].x & mask];
-            xg[4 * u + 1] = xin[pk[u].y & mask];
-            xg[4 * u + 2] = xin[pk[u].z & mask];
-            xg[4 * u + 3] = xin[pk[u].w & mask];
-#endif
-        }
-#pragma unroll
-        for (int u = 0; u < TU; ++u) if (on[u]) {
-            prod[pk[u].x >> lw] = vv[u].x * xg[4 * u + 0];
-            prod[pk[u].y >> lw] = vv[u].y * xg[4 * u + 1];
-            prod[pk[u].z >> lw] = vv[u].z * xg[4 * u + 2];
-            prod[pk[u].w >> lw] = vv[u].w * xg[4 * u + 3];
-        }
-    };
-    const size_t tile0 = (size_t)b * npanel;
-    const bool has_panels = p_lo < vtotal;             // (the host never launches a group without panels)
-    u32x4 pk[TU];
-    V4 vv[TU];
-    int i0 = has_panels ? tile_ptr[tile0 + pmap(p_lo)] : 0;
-    int i1 = has_panels ? tile_ptr[tile0 + pmap(p_lo) + 1] : 0;
-    load_into(pk, vv, i0, i1);
-
-#ifdef PDLP_STAMPS     /* diagnostic build (tools/ablate_tiled.sh): where a tile's cycles go; never shipped */
-    unsigned long long st_p1 = 0, st_s1 = 0, st_p2 = 0, st_s2 = 0, st_t;
-#define STAMP(acc) do { const unsigned long long n_ = __builtin_readcyclecounter(); acc += n_ - st_t; st_t = n_; } while (0)
-    st_t = __builtin_readcyclecounter();
-#else
-#define STAMP(acc) do { } while (0)
-#endif
-    for (int v = p_lo; v < p_hi; ++v) {
-        const int p = pmap(v);
-        const size_t tile = tile0 + p;
-        const T* __restrict__ xin = vin + ((size_t)p << lw);
-        int i0n = i1, i1n = i1;                                                  // the next tile (empty after the last)
-        if (v + 1 < p_hi) {
-            const int pn = pmap(v + 1);
-            i0n = tile_ptr[tile0 + pn];
-            i1n = tile_ptr[tile0 + pn + 1];
-        }
-        // segment lengths (4 bits each) of this thread's rows: row i of lane l of wave w is row w*64*rpt + i*64 + l
-        // of the row block, so the 64 lanes of a wave sit on 64 consecutive rows for every i
-        uint32_t cw[TCW];
-        const uint32_t* cp = tcnt + (tile * TNT + tid) * TCW;
-        uint32_t total = 0;
-#pragma unroll
-        for (int q = 0; q < TCW; ++q) {
-            cw[q] = __builtin_nontemporal_load(cp + q);
-            const uint32_t n2 = (cw[q] & 0x0f0f0f0fu) + ((cw[q] >> 4) & 0x0f0f0f0fu);
-            total += (n2 * 0x01010101u) >> 24;
-        }
-        total = wave_incl_scan_u32(total);
-        if (lane == 63) wsum[wv] = (int)total;           // items of this wave's rows in this tile
-        // pass 1, one register group at a time; the next group (of this tile or of the next) is loaded as soon as
-        // the current one is consumed
-        for (int g0 = i0; g0 < i1; g0 += TGRP) {
-            consume(pk, vv, g0, i1, xin);
-            if (g0 + TGRP < i1) load_into(pk, vv, g0 + TGRP, i1);
-            else load_into(pk, vv, i0n, i1n);
-        }
-        if (i0 >= i1) load_into(pk, vv, i0n, i1n);       // (an empty tile consumed nothing)
-        STAMP(st_p1);
-        __syncthreads();
-        STAMP(st_s1);
-        int sb = 0;
-#pragma unroll
-        for (int w = 0; w < TNT / 64; ++w) sb += (w < wv) ? wsum[w] : 0;
-        uint32_t sbase = (uint32_t)__builtin_amdgcn_readfirstlane(sb);      // first slot of this wave's rows
-        // pass 2: segment sums.  The slots are in row order, so for a given i the 64 rows of the wave own one
-        // contiguous run of slots: a row's first slot is the wave's running base plus the exclusive scan of the
-        // lanes' counts.  Four row indices are scanned at once (8-bit fields of one word; the format guarantees
-        // that 64 consecutive rows hold fewer than 256 items of a tile).  Consecutive lanes then read (nearly)
-        // consecutive LDS words -- the earlier thread-owns-consecutive-rows mapping put lanes ~26 words apart
-        // and paid 4-way bank conflicts on every read.  The first four items of every row are read
-        // unconditionally and selected by the row's count (no load-to-use chains, no exec masking; reading past
-        // a short row touches the next rows' items or the 8-word tail of the buffer); longer segments (0.06 % of
-        // the (row, tile) pairs at 0.65 items per pair) finish in a loop.
-#pragma unroll
-        for (int q = 0; q < TCW; ++q) {
-            if (8 * q < rpt) {
-                const uint32_t cE = cw[q] & 0x0f0f0f0fu, cO = (cw[q] >> 4) & 0x0f0f0f0fu;     // rows 8q+{0,2,4,6} | 8q+{1,3,5,7}
-                const uint32_t sE = wave_incl_scan_u32(cE), sO = wave_incl_scan_u32(cO);
-                const uint32_t tE = (uint32_t)__builtin_amdgcn_readlane((int)sE, 63), tO = (uint32_t)__builtin_amdgcn_readlane((int)sO, 63);
-                const uint32_t eE = sE - cE, eO = sO - cO;                                    // exclusive, field by field
-                constexpr int RG = sizeof(T) == 8 ? 2 : 4;      // rows advanced together (register budget)
-#pragma unroll
-                for (int g = 0; g < 8 / RG; ++g) {
-                    if (8 * q + RG * g < rpt) {         // counts of rows >= rpt are zero
-                        int cc[RG], oo[RG];
-#pragma unroll
-                        for (int z = 0; z < RG; ++z) {
-                            const int j = (RG * g + z) >> 1;                                  // field
-                            const bool odd = (RG * g + z) & 1;
-                            cc[z] = (int)(((odd ? cO : cE) >> (8 * j)) & 0xffu);
-                            oo[z] = (int)(sbase + (((odd ? eO : eE) >> (8 * j)) & 0xffu));
-                            sbase += ((odd ? tO : tE) >> (8 * j)) & 0xffu;
-                        }
-                        T v[RG * 4];
-#pragma unroll
-                        for (int z = 0; z < RG; ++z)
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) v[4 * z + k] = prod[oo[z] + k];
-#pragma unroll
-                        for (int z = 0; z < RG; ++z) {
-                            const int c = cc[z];
-                            T sum = c > 0 ? v[4 * z] : (T)0;
-                            sum += c > 1 ? v[4 * z + 1] : (T)0;
-                            sum += c > 2 ? v[4 * z + 2] : (T)0;
-                            sum += c > 3 ? v[4 * z + 3] : (T)0;
-                            if (c > 4)
-                                for (int k = 4; k < c; ++k) sum += prod[oo[z] + k];
-                            acc[8 * q + RG * g + z] += sum;
-                        }
-                    }
-                }
-            }
-        }
-        STAMP(st_p2);
-        __syncthreads();
-        STAMP(st_s2);
-        i0 = i0n;
-        i1 = i1n;
-    }
-#ifdef PDLP_STAMPS
-    if (lane == 0 && (b % 97) == 0 && (wv == 0 || wv == 5))
-        printf("block %d wave %d: pass1 %llu  sync1 %llu  pass2 %llu  sync2 %llu cycles over %d tiles\n", b, wv, st_p1, st_s1, st_p2, st_s2,
-               p_hi - p_lo);
-#endif
-    // The row sums sit in registers, lane l of wave w holding rows w*64*rpt + i*64 + l: for every i the lanes are
-    // on consecutive rows, so the epilogue (or the store of the partial sums) is coalesced straight from registers.
-    const int rb = TNT * rpt;
-    const int row0 = b * rb + wv * 64 * rpt + lane;
-    if (!FUSED) {
-        T* __restrict__ rs = rowsum + (size_t)(slot0 + grp) * rs_stride;
-#pragma unroll
-        for (int r = 0; r < TRPT_MAX; ++r)
-            if (r < rpt && row0 + 64 * r < nrows) rs[row0 + 64 * r] = acc[r];
-        return;
-    }
-    double accd[NACC] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int r = 0; r < TRPT_MAX; ++r)
-        if (r < rpt && row0 + 64 * r < nrows) epi(row0 + 64 * r, acc[r], accd);
-    if (Epi::NA > 0) {
-#pragma unroll
-        for (int r = 0; r < Epi::NA; ++r) {
-            double v = accd[r];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += shfl_xor_t(v, off);
-            __syncthreads();
-            if (lane == 0) dred8[wv] = v;
-            __syncthreads();
-            if (tid == 0) {
-                double t = 0.0;
-                for (int w = 0; w < TNT / 64; ++w) t += dred8[w];
-                partials[(size_t)b * NACC + r] = t;
-            }
-        }
-    }
-}
-
-// epilogue of the split tiled kernel: row sum = sum over panel groups (fixed order), then the fused vector update
-template <typename T, class Epi>
-__global__ __launch_bounds__(BLOCK) void k_rowsum_epilogue(const T* __restrict__ rowsum, int groups, int64_t rs_stride,
-                                                           int nrows, Epi epi, double* __restrict__ partials)
-{
-    __shared__ double dred[4];
-    epi.load();
-    double acc[NACC] = {0.0, 0.0, 0.0, 0.0};
-    for (int row = blockIdx.x * BLOCK + threadIdx.x; row < nrows; row += gridDim.x * BLOCK) {
-        T s = __builtin_nontemporal_load(rowsum + row);
-        for (int g = 1; g < groups; ++g) s += __builtin_nontemporal_load(rowsum + (size_t)g * rs_stride + row);
-        epi(row, s, acc);
-    }
-    if (Epi::NA > 0) {
-#pragma unroll
-        for (int r = 0; r < Epi::NA; ++r) {
-            const double v = block_sum(acc[r], dred);
-            if (threadIdx.x == 0) partials[(size_t)blockIdx.x * NACC + r] = v;
-        }
-    }
-}
-
-// red[off + r] = sum over blocks of partials[b][r]   (one workgroup; fixed order => deterministic)
-__global__ __launch_bounds__(BLOCK) void k_finalize(const double* __restrict__ partials, int nblocks, int na,
-                                                    double* __restrict__ red, int off)
-{
-    __shared__ double dred[4];
-    for (int r = 0; r < na; ++r) {
-        double s = 0.0;
-        for (int b = threadIdx.x; b < nblocks; b += BLOCK) s += partials[(size_t)b * NACC + r];
-        s = block_sum(s, dred);
-        if (threadIdx.x == 0) red[off + r] = s;
-        __syncthreads();
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// scalar kernels (one thread): the reference keeps eta/omega as 0-dim tensors of the working dtype
-// ------------------------------------------------------------------------------------------------
-template <typename T> __global__ void k_set_step(double* sc, double eta, double omega, double theta, double k)
-{
-    const T e = (T)eta, w = (T)omega, th = (T)theta;
-    sc[S_ETA] = (double)e;
-    sc[S_OMEGA] = (double)w;
-    sc[S_THETA] = (double)th;
-    sc[S_TAU] = (double)(T)(e / w);             // step.py:27 / :74
-    sc[S_SIGMA] = (double)(T)(e * w);           // step.py:34 / :75
-    sc[S_INV1PT] = (double)(T)((T)1 / ((T)1 + th));
-    sc[S_K] = k;
-}
-
-// omega <- new primal weight (enhancements.py:77); tau, sigma follow from the eta currently on the device
-template <typename T> __global__ void k_set_omega(double* sc, double omega)
-{
-    const T e = (T)sc[S_ETA], w = (T)omega;
-    sc[S_OMEGA] = (double)w;
-    sc[S_TAU] = (double)(T)(e / w);
-    sc[S_SIGMA] = (double)(T)(e * w);
-}
-
-__global__ void k_reset_average(double* sc)
-{
-    sc[S_WPEND] = 0.0;
-    sc[S_ETASUM] = 0.0;
-}
-
-// fixed step: eta_total += eta, k += 1, `iters` times (pdhg.py:76,109) in the working precision
-template <typename T> __global__ void k_fixed_advance(double* sc, int iters)
-{
-    T s = (T)sc[S_ETASUM];
-    const T e = (T)sc[S_ETA];
-    for (int i = 0; i < iters; ++i) s = s + e;
-    sc[S_ETASUM] = (double)s;
-    sc[S_K] += (double)iters;
-}
-
-// adaptive rule, step.py:91-115 with quirk Q1 (one trial; a rejected step is kept), then
-// pdhg.py:107-112: weight of the new iterate, eta_total, eta <- eta_hat.
-template <typename T> __device__ void adaptive_rule(double* sc, const double* red)
-{
-    const T eta = (T)sc[S_ETA], omega = (T)sc[S_OMEGA];
-    const double k1 = sc[S_K] + 1.0;                       // the reference's 1-based k of this step
-    const T den = (T)2 * (T)red[2];                        // step.py:96
-    T eta_bar, t1;
-    if (den != (T)0) {                                     // step.py:99-102
-        const T nx = (T)sqrt(red[0]), ny = (T)sqrt(red[1]);
-        const T num = omega * (nx * nx) + (ny * ny) / omega;
-        eta_bar = num / (T)fabs((double)den);
-        t1 = (T)(1.0 - pow(k1 + 1.0, -0.3)) * eta_bar;
-    } else {                                               // step.py:104-105
-        eta_bar = (T)INFINITY;
-        t1 = (T)INFINITY;
-    }
-    const T t2 = (T)(1.0 + pow(k1 + 1.0, -0.6)) * eta;     // step.py:107
-    const T eta_p = t1 < t2 ? t1 : t2;                     // step.py:108
-    const bool accept = eta <= eta_bar;                    // step.py:110
-    const T w = accept ? eta : eta_p;                      // first returned value (:111 / :115)
-    sc[S_WPEND] = (double)w;
-    sc[S_ETASUM] = (double)(T)((T)sc[S_ETASUM] + w);       // pdhg.py:109
-    sc[S_ETA] = (double)eta_p;                             // pdhg.py:112
-    sc[S_TAU] = (double)(T)(eta_p / omega);
-    sc[S_SIGMA] = (double)(T)(eta_p * omega);
-    sc[S_K] = k1;
-    sc[S_ACCEPT] = accept ? 1.0 : 0.0;
-    sc[S_ETABAR] = (double)eta_bar;
-    sc[S_DEN] = (double)den;
-}
-
-template <typename T> __global__ void k_adaptive_update(double* sc, const double* red) { adaptive_rule<T>(sc, red); }
-
-// single-rank fusion of pdlp_adaptive_reduce + pdlp_adaptive_update
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_adaptive_reduce_update(const double* __restrict__ pa, int na_blocks,
-                                                                  const double* __restrict__ pb, int nb_blocks,
-                                                                  double* __restrict__ red, double* __restrict__ sc, int update)
-{
-    __shared__ double dred[4];
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int b = threadIdx.x; b < na_blocks; b += BLOCK) s0 += pa[(size_t)b * NACC];
-    for (int b = threadIdx.x; b < nb_blocks; b += BLOCK) {
-        s1 += pb[(size_t)b * NACC];
-        s2 += pb[(size_t)b * NACC + 1];
-    }
-    s0 = block_sum(s0, dred);
-    s1 = block_sum(s1, dred);
-    s2 = block_sum(s2, dred);
-    if (threadIdx.x == 0) {
-        red[0] = s0; red[1] = s1; red[2] = s2;
-        if (update) adaptive_rule<T>(sc, red);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// vector kernels
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_flush(int64_t n, T* __restrict__ sum, const T* __restrict__ v, const double* sc)
-{
-    const T w = (T)sc[S_WPEND];
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) sum[i] += w * v[i];
-}
-
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_average(int64_t n, T* __restrict__ avg, const T* __restrict__ sum, const double* sc)
-{
-    const T s = (T)sc[S_ETASUM];
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) avg[i] = sum[i] / s;
-}
-
-__global__ void k_clear_pending(double* sc) { sc[S_WPEND] = 0.0; }
-
-// lam = project_lambda_box(g) (helpers.py:21-37) with the bound classes read off l, u
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_project_lambda(int64_t n, const T* __restrict__ g, const T* __restrict__ l,
-                                                          const T* __restrict__ u, T* __restrict__ out)
-{
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
-        const T lo = l[i], hi = u[i], gi = g[i];
-        const bool ninf = isinf(lo) && lo < (T)0, pinf = isinf(hi) && hi > (T)0;
-        out[i] = (ninf && pinf) ? (T)0 : (ninf ? (gi < (T)0 ? gi : (T)0) : (pinf ? (gi > (T)0 ? gi : (T)0) : gi));
-    }
-}
-
-// out = a - b
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_sub(int64_t n, T* __restrict__ out, const T* __restrict__ a, const T* __restrict__ b)
-{
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) out[i] = a[i] - b[i];
-}
-
-// partials[b][0] = sum (a-b)^2 (b may be null: sum a^2)
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_sqdiff(int64_t n, const T* __restrict__ a, const T* __restrict__ b,
-                                                  double* __restrict__ partials)
-{
-    __shared__ double dred[4];
-    double s = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
-        const T d = b ? a[i] - b[i] : a[i];
-        s += (double)d * (double)d;
-    }
-    s = block_sum(s, dred);
-    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * NACC] = s;
-}
-
-// v /= sqrt(red[idx])  (power iteration normalisation, helpers.py:50)
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_div_by_norm(int64_t n, T* __restrict__ v, const double* __restrict__ red, int idx)
-{
-    const T nb = (T)sqrt(red[idx]);
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) v[i] = v[i] / nb;
-}
-
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_muldiv(int64_t n, T* __restrict__ a, const T* __restrict__ b, int op)
-{
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK)
-        a[i] = op ? a[i] / b[i] : a[i] * b[i];
-}
-
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_max_dev_from_one(int64_t n, const T* __restrict__ v, double* __restrict__ out)
-{
-    __shared__ double dred[4];
-    double mx = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
-        const T d = (T)fabs((double)((T)1 - v[i]));
-        mx = (double)d > mx ? (double)d : mx;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double o = shfl_xor_t(mx, off);
-        mx = o > mx ? o : mx;
-    }
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) dred[w] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < 4; ++k) mx = dred[k] > mx ? dred[k] : mx;
-        // non-negative doubles order like their bit patterns
-        atomicMax((unsigned long long*)out, (unsigned long long)__double_as_longlong(mx));
-    }
-}
-
-// ---- Ruiz building blocks: 8 lanes per row ------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_row_scale_factors(int64_t rows, const int32_t* __restrict__ rp,
-                                                             const T* __restrict__ va, T eps, T* __restrict__ norm)
-{
-    const int64_t g = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 3;
-    const int lt = threadIdx.x & 7;
-    const int64_t stride = ((int64_t)gridDim.x * BLOCK) >> 3;
-    for (int64_t i = g; i < ((rows + stride - 1) / stride) * stride; i += stride) {
-        T mx = (T)0;
-        if (i < rows)
-            for (int p = rp[i] + lt; p < rp[i + 1]; p += 8) {
-                const T a = (T)fabs((double)va[p]);
-                mx = a > mx ? a : mx;
-            }
-        for (int off = 4; off > 0; off >>= 1) {
-            const T o = shfl_xor_t(mx, off);
-            mx = o > mx ? o : mx;
-        }
-        if (i < rows && lt == 0) {
-            const T r = (T)sqrt((double)mx);          // enhancements.py:49 / :54
-            norm[i] = r < eps ? (T)1 : r;             // :50 / :55
-        }
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_div_rows(int64_t rows, const int32_t* __restrict__ rp, T* __restrict__ va,
-                                                    const T* __restrict__ norm)
-{
-    const int64_t g = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 3;
-    const int lt = threadIdx.x & 7;
-    const int64_t stride = ((int64_t)gridDim.x * BLOCK) >> 3;
-    for (int64_t i = g; i < rows; i += stride) {
-        const T r = norm[i];
-        for (int p = rp[i] + lt; p < rp[i + 1]; p += 8) va[p] = va[p] / r;
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_div_cols(int64_t nnz, const int32_t* __restrict__ ci, T* __restrict__ va,
-                                                    const T* __restrict__ norm)
-{
-    for (int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x; p < nnz; p += (int64_t)gridDim.x * BLOCK)
-        va[p] = va[p] / norm[ci[p]];
-}
+#include "pdlp_epilogues.inc"
+#include "pdlp_kernel_csr.inc"
+#include "pdlp_kernel_tiled.inc"
+#include "pdlp_kernels_small.inc"
 
 // ------------------------------------------------------------------------------------------------
 // host side
