@@ -40,12 +40,12 @@ def _gap(res: dict) -> float:
 
 def fishnet(eng: PdlpEngine, pts: torch.Tensor, s: int = 2, k: int = 32, eta: Optional[float] = None,
             generator: Optional[torch.Generator] = None, b0: Optional[torch.Tensor] = None):
-    """``fishnet`` (:65-159) on an engine; ``pts`` is n x j on the host.  Returns (x, y) flattened on the device."""
+    """``fishnet`` (:65-159) on an engine; ``pts`` is n x j (moved to the device).  Returns (x, y) flattened on the device."""
     dev, dt = eng.device, eng.dtype
-    pts = pts.to(torch.float32)
+    pts = pts.to(device=dev, dtype=dt)                                # the population lives on the device (n x j, m x j)
     j = pts.shape[1]
     # pts_y = K @ pts (:100)
-    ys = torch.stack([eng.spmv(pts[:, p].to(dev), False).cpu() for p in range(j)], dim=1)
+    ys = torch.stack([eng.spmv(pts[:, p].contiguous(), False) for p in range(j)], dim=1)
     if eta is None:                                                   # init_PDHG_vars :161-189
         if b0 is None:
             b0 = torch.randn(eng.n, generator=generator, dtype=torch.float32)
@@ -57,13 +57,12 @@ def fishnet(eng: PdlpEngine, pts: torch.Tensor, s: int = 2, k: int = 32, eta: Op
     while j > 1:                                                      # :105
         gaps = []
         for p in range(j):                                            # k PDHG steps on every point (:107-109)
-            eng.set_iterate(pts[:, p].to(dev), ys[:, p].to(dev))
+            eng.set_iterate(pts[:, p].contiguous(), ys[:, p].contiguous())
             eng.iterate(k, False)
-            x, y = eng.get_iterate(N.CUR)
-            pts[:, p], ys[:, p] = x.cpu(), y.cpu()
+            pts[:, p], ys[:, p] = eng.get_iterate(N.CUR)
             gaps.append(_gap(eng.kkt(N.CUR, omega)))                  # get_best_pts :191-252 (duality gap only)
         old_j = j
-        order = torch.argsort(torch.tensor(gaps, dtype=torch.float32))                   # ascending (:238)
+        order = torch.argsort(torch.tensor(gaps, dtype=torch.float32)).to(dev)           # ascending (:238)
         keep = max(1, old_j // s)
         pts, ys = pts[:, order][:, :keep].clone(), ys[:, order][:, :keep].clone()
         new_j = keep
@@ -72,7 +71,7 @@ def fishnet(eng: PdlpEngine, pts: torch.Tensor, s: int = 2, k: int = 32, eta: Op
             new_x, new_y = [], []
             for _ in range(old_j - new_j - 1):
                 w = torch.rand(new_j, generator=generator)
-                w = w / w.sum()
+                w = (w / w.sum()).to(device=dev, dtype=dt)
                 new_x.append(pts @ w.view(-1, 1))
                 new_y.append(ys @ w.view(-1, 1))
             if new_x:
@@ -80,7 +79,7 @@ def fishnet(eng: PdlpEngine, pts: torch.Tensor, s: int = 2, k: int = 32, eta: Op
                 ys = torch.cat([ys] + new_y + [mid_y], dim=1)
         j = pts.shape[1]
         i += 1
-    return pts.flatten().to(dev, dt), ys.flatten().to(dev, dt)
+    return pts.flatten(), ys.flatten()
 
 
 def spectral_cast(K, c, q, l, u, m_ineq, k, s=2, i=5, device=None, generator: Optional[torch.Generator] = None):
