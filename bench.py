@@ -46,7 +46,7 @@ def parse():
     p.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-rows", type=int, default=500_000)
-    p.add_argument("--kernel-reps", type=int, default=10)
+    p.add_argument("--kernel-reps", type=int, default=20)
     return p.parse_args()
 
 
@@ -59,18 +59,25 @@ def algorithmic_bytes(n, m, nnz, sv, si, adaptive):
     return primal, dual
 
 
-def time_kernel(eng, fn, reps):
-    """mean duration (ms) of one launch, HIP events on the stream the kernel runs on"""
-    stream = eng.stream
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    fn()
+def time_half_steps(eng, adaptive, reps):
+    """mean duration (ms) of the two fused half-step kernels, launched in the order an iteration launches them (primal,
+    dual, primal, ...: each starts with the caches in the state the other one left, as inside the timed region), HIP
+    events on the stream the library launches on"""
+    stream, a = eng.stream, int(adaptive)
+    primal = lambda: N.check(eng.lib.pdlp_primal_half(eng.h, a))
+    dual = lambda: N.check(eng.lib.pdlp_dual_half(eng.h, a))       # (flips the iterate buffers each launch: harmless here)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    evs = [(ev(), ev(), ev()) for _ in range(reps)]
+    primal(); dual()
     stream.synchronize()
-    for a, b in evs:
-        a.record(stream)
-        fn()
-        b.record(stream)
+    for e0, e1, e2 in evs:
+        e0.record(stream)
+        primal()
+        e1.record(stream)
+        dual()
+        e2.record(stream)
     stream.synchronize()
-    return sum(a.elapsed_time(b) for a, b in evs) / reps
+    return (sum(e0.elapsed_time(e1) for e0, e1, _ in evs) / reps, sum(e1.elapsed_time(e2) for _, e1, e2 in evs) / reps)
 
 
 def host_cores() -> int:
@@ -134,11 +141,8 @@ def measure_roofline(args, eng, dt, adaptive, world):
     nnz_kt = int(eng.KT[2].numel())
     b_primal, _ = algorithmic_bytes(nl, eng.m, nnz_kt, sv, si, adaptive)
     _, b_dual = algorithmic_bytes(eng.n, ml, nnz_k, sv, si, adaptive)
-    a = int(adaptive)
     eng.iterate(1, adaptive)        # (leaves no K'y behind from a restart check: the primal half-step below is the full kernel)
-    ms_primal = time_kernel(eng, lambda: N.check(eng.lib.pdlp_primal_half(eng.h, a)), args.kernel_reps)
-    # the dual kernel flips the iterate buffers each launch: harmless for timing
-    ms_dual = time_kernel(eng, lambda: N.check(eng.lib.pdlp_dual_half(eng.h, a)), args.kernel_reps)
+    ms_primal, ms_dual = time_half_steps(eng, adaptive, args.kernel_reps)
     kfam = lambda t: "k_tiled_fused" if eng.tiles[t] is not None else "k_csr_fused"
     if ms_primal >= ms_dual:
         kname, kms, kbytes = f"{kfam(1)}<PrimalEpi> (K'y + primal update)", ms_primal, b_primal
