@@ -211,6 +211,17 @@ int pdlp_infeas_local(pdlp_handle h, double tol);
  *          l_f'dlam_minus + u_f'dlam_plus }.  Synchronises the stream. */
 int pdlp_infeas_finish(pdlp_handle h, double tol, int32_t* status, double diag[8]);
 
+/* ---- populations of points (fishnet warm start, spectral_casting.py:65-159) -------------------- */
+/* nvp (8, 16 or 32) points advance together; X is [n][nvp], Y is [m][nvp], row-major device arrays in the problem's
+ * precision (single GPU).  One pass over each matrix serves all nvp points: an item contributes to nvp row sums with
+ * one coalesced line of the population matrix.
+ * pdlp_mv_steps: `steps` fixed-step PDHG iterations on every point, in place -- PDHG_step spectral_casting.py:254-293
+ *   (= fixed_one_step_pdhg per column).  work: (2 n + m) * nvp values.
+ * pdlp_mv_gap: gaps[v] = adjusted dual objective - primal objective of point v (signed) -- get_best_pts
+ *   spectral_casting.py:215-234.  work: 256 * nvp * 4 + nvp * 4 doubles.  gaps: host array of nvp.  Synchronises. */
+int pdlp_mv_steps(pdlp_handle h, int nvp, int steps, double eta, double omega, double theta, void* X, void* Y, void* work);
+int pdlp_mv_gap(pdlp_handle h, int nvp, const void* X, const void* Y, void* work, double* gaps);
+
 /* ---- plain products (power iteration helpers.py:41-51, tests) ------------------------------- */
 /* out_local = K in_full (transpose=0, out has row1-row0 values) or K' in_full (transpose=1) */
 int pdlp_spmv(pdlp_handle h, int transpose, const void* in_full, void* out_local);

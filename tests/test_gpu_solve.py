@@ -103,3 +103,62 @@ def test_fishnet_warm_start_matches_the_oracle_restatement(golden):
     xs, obj, k, n, j, status, _ = tp.pdlp_algorithm(K, int(a["m_ineq"]), t(a["c"]), t(a["q"]), t(a["l"]), t(a["u"]), "cuda:0",
                                                     verbose=False, adaptive=True, primal_update=True, x_init=x, y_init=y, seed=1)
     assert status == "Solved" and abs(obj - float(g.group("mixed_400x300/fixed_nopw")["opt_obj"])) < 0.2
+
+
+@pytest.mark.parametrize("j", [8, 16, 32])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_population_kernels_match_the_single_vector_path(golden, j, dtype):
+    """pdlp_mv_steps / pdlp_mv_gap (PDHG_step spectral_casting.py:254-293, get_best_pts :215-234): every column of the
+    population equals the same point taken through fixed_one_step_pdhg and the KKT pass, and the oracle's"""
+    from oracle import oracle as orc
+    from torchpdlp_amd import _native as N
+    g = golden("solve_trace.npz")
+    a = g.group("mixed_400x300")
+    npd = np.float32 if dtype == torch.float32 else np.float64
+    o = orc.OracleLP(a["m"], a["n"], a["m_ineq"], a["rowptr"], a["colidx"], a["val"], a["c"], a["q"], a["l"], a["u"], dtype=npd)
+    orc.set_threads(1)
+    t = lambda v, dt=dtype: torch.tensor(np.asarray(v), dtype=dt, device="cuda:0")
+    K = tp.CsrPair(int(a["m"]), int(a["n"]), t(a["rowptr"], torch.int32), t(a["colidx"], torch.int32), t(a["val"]))
+    eng = tp.PdlpEngine.from_full(K, t(a["c"]), t(a["q"]), t(a["l"]), t(a["u"]), int(a["m_ineq"]))
+    gen = torch.Generator().manual_seed(3 + j)
+    X = torch.randn(300, j, generator=gen, dtype=torch.float64).to("cuda:0", dtype)
+    Y = torch.randn(400, j, generator=gen, dtype=torch.float64).to("cuda:0", dtype)
+    X0, Y0 = X.clone(), Y.clone()
+    eta, omega = 0.07, 1.3
+    for steps in (1, 6):                                    # odd and even: the buffers alternate inside the call
+        X, Y = X0.clone(), Y0.clone()
+        eng.mv_steps(X, Y, steps, eta, omega, 1.0)
+        gaps = eng.mv_gap(X, Y)
+        tol = 2e-5 if dtype == torch.float32 else 1e-12
+        for p in (0, j // 2, j - 1):
+            eng.set_iterate(X0[:, p].contiguous(), Y0[:, p].contiguous())
+            eng.set_step(eta, omega, 1.0, 0)
+            eng.iterate(steps, False)
+            xs, ys = eng.get_iterate(N.CUR)
+            np.testing.assert_allclose(X[:, p].cpu().numpy(), xs.cpu().numpy(), rtol=tol, atol=tol)
+            np.testing.assert_allclose(Y[:, p].cpu().numpy(), ys.cpu().numpy(), rtol=tol, atol=tol)
+            xo, yo = X0[:, p].cpu().numpy(), Y0[:, p].cpu().numpy()
+            for _ in range(steps):
+                xo, yo = o.step_fixed(xo, yo, eta, omega, 1.0)
+            np.testing.assert_allclose(X[:, p].cpu().numpy(), xo, rtol=5 * tol, atol=5 * tol)
+            ref = o.kkt(xo, yo, omega)
+            scale = 1 + abs(float(ref["p"])) + abs(float(ref["d_adj"]))
+            assert abs(gaps[p] - float(ref["gap"])) <= 20 * tol * scale
+            assert abs(gaps[p] - eng.kkt(N.CUR, omega)["gap"]) <= 20 * tol * scale
+    with pytest.raises(ValueError):
+        eng.mv_steps(X[:, :5].contiguous(), Y[:, :5].contiguous(), 1, eta, omega)
+
+
+def test_fishnet_population_path_equals_point_by_point(golden):
+    """32 points through the population kernels and through the single-vector kernels: same survivor"""
+    g = golden("solve_trace.npz")
+    a = g.group("mixed_400x300")
+    t = lambda v, dt=torch.float32: torch.tensor(np.asarray(v), dtype=dt, device="cuda:0")
+    K = tp.CsrPair(int(a["m"]), int(a["n"]), t(a["rowptr"], torch.int32), t(a["colidx"], torch.int32), t(a["val"]))
+    eng = tp.PdlpEngine.from_full(K, t(a["c"]), t(a["q"]), t(a["l"]), t(a["u"]), int(a["m_ineq"]))
+    pts, r = tp.sample_points(eng, 5, torch.Generator().manual_seed(11))
+    assert pts.shape == (300, 32)
+    outs = [tp.fishnet(eng, pts.clone(), s=2, k=8, eta=0.9 / r, generator=torch.Generator().manual_seed(12), multi_vector=mv)
+            for mv in (True, False)]
+    np.testing.assert_allclose(outs[0][0].cpu().numpy(), outs[1][0].cpu().numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(outs[0][1].cpu().numpy(), outs[1][1].cpu().numpy(), rtol=2e-4, atol=2e-4)

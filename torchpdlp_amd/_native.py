@@ -74,6 +74,8 @@ SIGNATURES = {
     "pdlp_infeas_begin": (_I, [_H]),
     "pdlp_infeas_local": (_I, [_H, _D]),
     "pdlp_infeas_finish": (_I, [_H, _D, C.POINTER(C.c_int32), C.POINTER(_D)]),
+    "pdlp_mv_steps": (_I, [_H, _I, _I, _D, _D, _D, _P, _P, _P]),
+    "pdlp_mv_gap": (_I, [_H, _I, _P, _P, _P, C.POINTER(_D)]),
     "pdlp_spmv": (_I, [_H, _I, _P, _P]),
     "pdlp_power_iteration": (_I, [_H, _P, _I, _P, _P, C.POINTER(_D)]),
     "pdlp_csr_row_scale_factors": (_I, [_I, _I64, _P, _P, _D, _P, _P]),

@@ -73,6 +73,7 @@ template <typename T> __device__ __forceinline__ T block_sum(T v, T* buf)
 #include "pdlp_kernel_csr.inc"
 #include "pdlp_kernel_tiled.inc"
 #include "pdlp_kernels_small.inc"
+#include "pdlp_kernel_mv.inc"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -543,6 +544,78 @@ template <typename T> int power_iteration_t(pdlp_handle h, const void* b0, int i
     HIP_TRY(hipStreamSynchronize(h->stream));
     *sigma = (double)(T)std::sqrt(r);
     return PDLP_OK;
+}
+
+// ---- population kernels (fishnet) ---------------------------------------------------------------
+constexpr int MV_GAP_GRID = 256;
+inline int mv_grid(int64_t rows, int nvp)
+{
+    const int64_t per_block = (int64_t)(64 / nvp) * (BLOCK / 64);
+    const int64_t g = (rows + per_block - 1) / per_block;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+template <typename T, int NVP> int mv_steps_n(pdlp_handle h, int steps, double eta, double omega, double theta, T* X, T* Y, T* work)
+{
+    const int64_t n = h->p.n, m = h->p.m;
+    const T e = (T)eta, w = (T)omega;
+    const T tau = (T)(e / w), sigma = (T)(e * w);                 // (rounded like k_set_step)
+    T *Xa = X, *Xb = work, *Xbar = work + n * NVP, *Ya = Y, *Yb = work + 2 * n * NVP;
+    for (int s = 0; s < steps; ++s) {
+        PrimalMV<T> ep{Xa, Xb, Xbar, (const T*)h->p.c, (const T*)h->p.l, (const T*)h->p.u, tau, (T)theta};
+        hipLaunchKernelGGL((k_csr_mv<T, NVP, PrimalMV<T>>), dim3(mv_grid(n, NVP)), dim3(BLOCK), 0, h->stream, (int)n, h->p.KT_rowptr,
+                           h->p.KT_colidx, (const T*)h->p.KT_val, (const T*)Ya, ep, (double*)nullptr);
+        DualMV<T> ed{Ya, Yb, (const T*)h->p.q, sigma, h->ineq_end};
+        hipLaunchKernelGGL((k_csr_mv<T, NVP, DualMV<T>>), dim3(mv_grid(m, NVP)), dim3(BLOCK), 0, h->stream, (int)m, h->p.K_rowptr,
+                           h->p.K_colidx, (const T*)h->p.K_val, (const T*)Xbar, ed, (double*)nullptr);
+        T* t = Xa; Xa = Xb; Xb = t;
+        t = Ya; Ya = Yb; Yb = t;
+    }
+    HIP_TRY(hipGetLastError());
+    if (steps & 1) {
+        HIP_TRY(hipMemcpyAsync(X, Xa, (size_t)n * NVP * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(Y, Ya, (size_t)m * NVP * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+    }
+    return PDLP_OK;
+}
+
+template <typename T, int NVP> int mv_gap_n(pdlp_handle h, const T* X, const T* Y, double* work, double* gaps)
+{
+    const int64_t n = h->p.n, m = h->p.m;
+    const int ga = mv_grid(n, NVP) < MV_GAP_GRID ? mv_grid(n, NVP) : MV_GAP_GRID, gb = mv_grid(m, NVP) < MV_GAP_GRID ? mv_grid(m, NVP) : MV_GAP_GRID;
+    double* pa = work;                                   // [ga][NVP][3]
+    double* pb = work + (size_t)MV_GAP_GRID * NVP * 3;   // [gb][NVP][1]
+    double* out = pb + (size_t)MV_GAP_GRID * NVP;        // [NVP][3] then [NVP]
+    GapMV<T> eg{X, (const T*)h->p.c, (const T*)h->p.l, (const T*)h->p.u};
+    hipLaunchKernelGGL((k_csr_mv<T, NVP, GapMV<T>>), dim3(ga), dim3(BLOCK), 0, h->stream, (int)n, h->p.KT_rowptr, h->p.KT_colidx,
+                       (const T*)h->p.KT_val, Y, eg, pa);
+    hipLaunchKernelGGL((k_mv_dot<T, NVP>), dim3(gb), dim3(BLOCK), 0, h->stream, (int)m, (const T*)h->p.q, Y, pb);
+    hipLaunchKernelGGL(k_mv_finalize, dim3(1), dim3(BLOCK), 0, h->stream, pa, ga, NVP * 3, out);
+    hipLaunchKernelGGL(k_mv_finalize, dim3(1), dim3(BLOCK), 0, h->stream, pb, gb, NVP, out + NVP * 3);
+    HIP_TRY(hipGetLastError());
+    double r[32 * 4];
+    HIP_TRY(hipMemcpyAsync(r, out, (size_t)NVP * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int v = 0; v < NVP; ++v) {                      // get_best_pts :231-233 in the working precision
+        const T p = (T)r[3 * v], lp = (T)r[3 * v + 1], un = (T)r[3 * v + 2], d = (T)r[NVP * 3 + v];
+        const T adj = d + lp + un;
+        gaps[v] = (double)(T)(adj - p);
+    }
+    return PDLP_OK;
+}
+
+template <typename T> int mv_steps_t(pdlp_handle h, int nvp, int steps, double eta, double omega, double theta, void* X, void* Y, void* work)
+{
+    if (nvp == 8) return mv_steps_n<T, 8>(h, steps, eta, omega, theta, (T*)X, (T*)Y, (T*)work);
+    if (nvp == 16) return mv_steps_n<T, 16>(h, steps, eta, omega, theta, (T*)X, (T*)Y, (T*)work);
+    return mv_steps_n<T, 32>(h, steps, eta, omega, theta, (T*)X, (T*)Y, (T*)work);
+}
+
+template <typename T> int mv_gap_t(pdlp_handle h, int nvp, const void* X, const void* Y, void* work, double* gaps)
+{
+    if (nvp == 8) return mv_gap_n<T, 8>(h, (const T*)X, (const T*)Y, (double*)work, gaps);
+    if (nvp == 16) return mv_gap_n<T, 16>(h, (const T*)X, (const T*)Y, (double*)work, gaps);
+    return mv_gap_n<T, 32>(h, (const T*)X, (const T*)Y, (double*)work, gaps);
 }
 
 int check_problem(const pdlp_problem* p)
@@ -1116,6 +1189,20 @@ int pdlp_infeas_finish(pdlp_handle h, double tol, int32_t* status, double diag[8
     if (rc != PDLP_OK) return rc;
     *status = h->p.dtype == PDLP_F32 ? infeas_decide_t<float>(r, tol, diag) : infeas_decide_t<double>(r, tol, diag);
     return PDLP_OK;
+}
+
+int pdlp_mv_steps(pdlp_handle h, int nvp, int steps, double eta, double omega, double theta, void* X, void* Y, void* work)
+{
+    if (!h || !X || !Y || !work || steps < 0 || (nvp != 8 && nvp != 16 && nvp != 32)) return PDLP_ERR_INVALID;
+    if (h->nl != h->p.n || h->ml != h->p.m) return PDLP_ERR_STATE;
+    return DISPATCH(h, mv_steps_t, h, nvp, steps, eta, omega, theta, X, Y, work);
+}
+
+int pdlp_mv_gap(pdlp_handle h, int nvp, const void* X, const void* Y, void* work, double* gaps)
+{
+    if (!h || !X || !Y || !work || !gaps || (nvp != 8 && nvp != 16 && nvp != 32)) return PDLP_ERR_INVALID;
+    if (h->nl != h->p.n || h->ml != h->p.m) return PDLP_ERR_STATE;
+    return DISPATCH(h, mv_gap_t, h, nvp, X, Y, work, gaps);
 }
 
 int pdlp_spmv(pdlp_handle h, int transpose, const void* in_full, void* out_local)

@@ -299,6 +299,36 @@ class PdlpEngine:
         status = self.INFEAS_STATUS[st.value]
         return (status, list(diag)) if diagnostics else status
 
+    # ---- populations of points (fishnet) ------------------------------------------------------------------
+    MV_WIDTHS = (8, 16, 32)
+
+    def mv_steps(self, X: torch.Tensor, Y: torch.Tensor, steps: int, eta: float, omega: float, theta: float = 1.0):
+        """``steps`` fixed-step PDHG iterations on every column of X (n x j) / Y (m x j), in place -- PDHG_step
+        (spectral_casting.py:254-293); j in MV_WIDTHS, one pass over each matrix per step for all j points."""
+        j = self._mv_check(X, Y)
+        work = torch.empty((2 * self.n + self.m) * j, dtype=self.dtype, device=self.device)
+        N.check(self.lib.pdlp_mv_steps(self.h, j, int(steps), float(eta), float(omega), float(theta), X.data_ptr(), Y.data_ptr(),
+                                       work.data_ptr()), "pdlp_mv_steps")
+        self.stream.synchronize()           # (work is released on return)
+
+    def mv_gap(self, X: torch.Tensor, Y: torch.Tensor) -> list:
+        """signed duality gap (adjusted dual - primal objective) of every column -- get_best_pts (spectral_casting.py:215-234)"""
+        j = self._mv_check(X, Y)
+        work = torch.empty(256 * j * 4 + j * 4, dtype=torch.float64, device=self.device)
+        out = (C.c_double * j)()
+        N.check(self.lib.pdlp_mv_gap(self.h, j, X.data_ptr(), Y.data_ptr(), work.data_ptr(), out), "pdlp_mv_gap")
+        return list(out)
+
+    def _mv_check(self, X, Y) -> int:
+        if self.comm is not None:
+            raise N.PdlpError("the population kernels run on one GPU")
+        j = int(X.shape[1])
+        ok = (X.dim() == 2 and Y.dim() == 2 and X.shape == (self.n, j) and Y.shape == (self.m, j) and j in self.MV_WIDTHS
+              and X.is_contiguous() and Y.is_contiguous() and X.dtype == self.dtype == Y.dtype and X.device == self.device == Y.device)
+        if not ok:
+            raise ValueError(f"population of {tuple(X.shape)} / {tuple(Y.shape)}: need contiguous n x j and m x j, j in {self.MV_WIDTHS}")
+        return j
+
     # ---- products -----------------------------------------------------------------------------------
     def spmv(self, v_full: torch.Tensor, transpose: bool = False) -> torch.Tensor:
         """K v (or K' v) for this rank's rows; ``v_full`` must be complete."""

@@ -3,9 +3,11 @@
 keep the best 1/s by (signed) duality gap, on odd rounds breed the population back with random convex combinations
 plus the midpoint, until one point is left.
 
-The reference advances all points at once as an n x j matrix (``PDHG_step`` :254-293); the points are independent,
-so here each point runs through the same fused single-vector kernels the solver uses (``PdlpEngine.iterate`` /
-``kkt``).  Batching the points into one multi-vector pass over the matrix is future work.
+The reference advances all points at once as an n x j matrix (``PDHG_step`` :254-293).  Here populations of 8, 16 or
+32 points do the same on the device: the multi-vector kernels (``pdlp_mv_steps`` / ``pdlp_mv_gap``, csrc/pdlp_kernel_mv.inc)
+read each matrix once per step for all points, an item contributing to all j row sums with one coalesced line of the
+population matrix.  Smaller populations (the last rounds) and sharded problems run point by
+point through the fused single-vector kernels the solver uses (``PdlpEngine.iterate`` / ``kkt``).
 Randomness: the reference draws from the global torch RNG on the device; pass ``generator`` (a CPU generator) to
 pin the points and the breeding weights.
 """
@@ -39,7 +41,7 @@ def _gap(res: dict) -> float:
 
 
 def fishnet(eng: PdlpEngine, pts: torch.Tensor, s: int = 2, k: int = 32, eta: Optional[float] = None,
-            generator: Optional[torch.Generator] = None, b0: Optional[torch.Tensor] = None):
+            generator: Optional[torch.Generator] = None, b0: Optional[torch.Tensor] = None, multi_vector: bool = True):
     """``fishnet`` (:65-159) on an engine; ``pts`` is n x j (moved to the device).  Returns (x, y) flattened on the device."""
     dev, dt = eng.device, eng.dtype
     pts = pts.to(device=dev, dtype=dt)                                # the population lives on the device (n x j, m x j)
@@ -55,12 +57,17 @@ def fishnet(eng: PdlpEngine, pts: torch.Tensor, s: int = 2, k: int = 32, eta: Op
     eng.set_step(eta, omega, 1.0, 0)
     i = 0
     while j > 1:                                                      # :105
-        gaps = []
-        for p in range(j):                                            # k PDHG steps on every point (:107-109)
-            eng.set_iterate(pts[:, p].contiguous(), ys[:, p].contiguous())
-            eng.iterate(k, False)
-            pts[:, p], ys[:, p] = eng.get_iterate(N.CUR)
-            gaps.append(_gap(eng.kkt(N.CUR, omega)))                  # get_best_pts :191-252 (duality gap only)
+        if multi_vector and eng.comm is None and j in eng.MV_WIDTHS:  # all points in one pass over the matrices
+            pts, ys = pts.contiguous(), ys.contiguous()
+            eng.mv_steps(pts, ys, k, eta, omega, 1.0)                 # k PDHG steps on every point (:107-109)
+            gaps = eng.mv_gap(pts, ys)                                # get_best_pts :191-252 (duality gap only)
+        else:
+            gaps = []
+            for p in range(j):
+                eng.set_iterate(pts[:, p].contiguous(), ys[:, p].contiguous())
+                eng.iterate(k, False)
+                pts[:, p], ys[:, p] = eng.get_iterate(N.CUR)
+                gaps.append(_gap(eng.kkt(N.CUR, omega)))
         old_j = j
         order = torch.argsort(torch.tensor(gaps, dtype=torch.float32)).to(dev)           # ascending (:238)
         keep = max(1, old_j // s)
