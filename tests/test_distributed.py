@@ -86,19 +86,19 @@ def _cpu_worker(rank, world, port, ret):
         # an 8-double all-reduce like the KKT partial sums
         red = torch.tensor([float(rank + 1)] * 8, dtype=torch.float64)
         comm.all_reduce_sum(red)
-        assert red.tolist() == [3.0] * 8
+        assert red.tolist() == [world * (world + 1) / 2.0] * 8
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_step_equals_unsharded_cpu_gloo():
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_step_equals_unsharded_cpu_gloo(world):
     port = _free_port()
     with mp.Manager() as man:
         ret = man.dict()
         mp.spawn(_cpu_worker, args=(world, port, ret), nprocs=world, join=True)
-        assert dict(ret) == {0: "ok", 1: "ok"}
+        assert dict(ret) == {r: "ok" for r in range(world)}
 
 
 def test_block_partition_and_padding():
@@ -189,13 +189,13 @@ def _gpu_worker(rank, world, port, ret):
 
 
 @pytest.mark.gpu
-def test_two_ranks_on_one_gpu_match_single_rank():
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_sharing_one_gpu_match_single_rank(world):
     port = _free_port()
     with mp.Manager() as man:
         ret = man.dict()
         mp.spawn(_gpu_worker, args=(world, port, ret), nprocs=world, join=True)
-        assert dict(ret) == {0: "ok", 1: "ok"}
+        assert dict(ret) == {r: "ok" for r in range(world)}
 
 
 def _gpu_split_worker(rank, world, port, ret):
