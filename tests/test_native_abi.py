@@ -59,3 +59,26 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert lib.pdlp_vec_muldiv(7, 1, None, None, 0, None) == -1      # bad dtype code
     with pytest.raises(N.PdlpError):
         N.check(-1, "demo")
+
+
+def test_product_path_fails_loudly_off_the_gpu_and_without_the_library(monkeypatch, tmp_path):
+    """no CPU fallback anywhere in the package: a problem on the host, or a missing library, raises"""
+    import torch
+    import torchpdlp_amd as tp
+    lp = tp.gen_lp(40, 30, 3, seed=1, device="cpu")
+    K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
+    with pytest.raises(N.PdlpError, match="no CPU fallback"):
+        tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
+    if not torch.cuda.is_available():
+        with pytest.raises(Exception):                     # the reference-named operators need the device as well
+            tp.fixed_one_step_pdhg(lp.c.view(-1, 1) * 0, lp.q.view(-1, 1) * 0, lp.c, lp.q, K, lp.l, lp.u, lp.m_ineq, 0.1, 1.0, 1.0)
+    monkeypatch.setattr(N, "_lib", None)
+    monkeypatch.setattr(N, "LIB_PATH", str(tmp_path / "libpdlp_hip.so"))
+    with pytest.raises(N.PdlpError, match="not built"):
+        N.load()
+    # the oracle is test infrastructure: nothing under torchpdlp_amd/ imports it
+    pkg = os.path.join(ROOT, "torchpdlp_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            src = open(os.path.join(pkg, f)).read()
+            assert "import oracle" not in src and "from oracle" not in src, f
