@@ -5,8 +5,13 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one PDHG iteration of the production driver (torchpdlp_amd.solver.PdhgDriver): the two
-fused SpMV half-steps (+ the step-size rule when adaptive) with the reference's restart cadence inside
-the timed region -- three KKT evaluations every 40 iterations and the restart work when one fires.
+fused SpMV half-steps (+ the step-size rule when adaptive) at the reference's restart cadence -- a restart
+check (three KKT evaluations) every 40 iterations and the restart work when one fires.  The timed region is
+EXACTLY --steps iterations, starting right after a restart check (the warm-up is extended, untimed, to the next
+multiple of 40); it therefore holds floor(steps/40) checks.  So that the number does not depend on --steps, the
+cost of the (steps/40 - checks held) missing or surplus checks is added at the measured cost of one check
+(timed on the period that follows the timed region): value = steps / (elapsed + (steps/40 - checks) * check_s).
+For steps a multiple of 40 that is steps / elapsed exactly.  All three raw numbers are in "timing".
 The LP is resident in HBM before the clock starts.  Default workload = the one the metric is quoted
 on: 10M x 10M, density 1e-5 (100 non-zeros per row), float32 like the reference; it fits one GPU.
 With N > 1 the same instance is sharded (row blocks of K and K'), so scaling is strong.
@@ -127,10 +132,38 @@ def cpu_baseline(args, sv_dtype):
     kkt_s = time.time() - t1
     per_iter = step_s + 3.0 * kkt_s / 40.0            # the reference's restart cadence
     scale = (lp.nnz / float(args.nnz_per_row * (args.m or args.n)))
-    return dict(value=round(scale / per_iter, 4), unit="iterations/s", cores=cores, kind="port",
-                sample=f"oracle (C, OpenMP) on gen_lp({rows}x{rows}, {args.nnz_per_row} nnz/row, seed 0): "
-                       f"{iters} {args.mode} iterations at {step_s * 1e3:.1f} ms + KKT pass {kkt_s * 1e3:.1f} ms x3/40; "
-                       f"rate scaled by nnz ratio {scale:.4g} to the full workload")
+    out = dict(value=round(scale / per_iter, 4), unit="iterations/s", cores=cores, kind="port",
+               sample=f"oracle (C, OpenMP, CSR + pre-transposed CSR) on gen_lp({rows}x{rows}, {args.nnz_per_row} nnz/row, seed 0): "
+                      f"{iters} {args.mode} iterations at {step_s * 1e3:.1f} ms + KKT pass {kkt_s * 1e3:.1f} ms x3/40; "
+                      f"rate scaled by nnz ratio {scale:.4g} to the full workload")
+    # flavour (i) of SURVEY 8d: what the reference itself does on a CPU -- eager torch ops on a sparse-COO K with K.T @ y
+    try:
+        from oracle.torch_coo import TorchCooLP
+        torch.set_num_threads(cores)
+        rows2 = min(rows, 200_000)
+        lp2 = tp.gen_lp(rows2, rows2, args.nnz_per_row, seed=0, device="cpu", dtype=torch.float32)
+        t = TorchCooLP(lp2.m, lp2.n, lp2.m_ineq, lp2.rowptr, lp2.colidx, lp2.val, lp2.c, lp2.q, lp2.l, lp2.u)
+        xx, yy = torch.zeros(lp2.n, 1), torch.zeros(lp2.m, 1)
+        e, w = torch.tensor(0.01), torch.tensor(1.0)
+        stepf = (lambda k, xx, yy, e: t.step_adaptive(xx, yy, e, w, 1.0, k)[:2] + (e,)) if adaptive else \
+                (lambda k, xx, yy, e: t.step_fixed(xx, yy, e, w, 1.0) + (e,))
+        xx, yy, e = stepf(1, xx, yy, e)
+        t0, it2 = time.time(), 0
+        while it2 < 2 or (time.time() - t0 < 8.0 and it2 < 50):
+            xx, yy, e = stepf(it2 + 2, xx, yy, e)
+            it2 += 1
+        s2 = (time.time() - t0) / it2
+        t1 = time.time()
+        t.kkt(xx, yy, w)
+        k2 = time.time() - t1
+        sc2 = lp2.nnz / float(args.nnz_per_row * (args.m or args.n))
+        out["torch_coo"] = dict(value=round(sc2 / (s2 + 3.0 * k2 / 40.0), 4), unit="iterations/s", cores=cores, kind="port",
+                                sample=f"eager torch ops on sparse-COO K (K.T @ y, three products per adaptive step like the reference) on "
+                                       f"gen_lp({rows2}x{rows2}, {args.nnz_per_row} nnz/row): {it2} iterations at {s2 * 1e3:.0f} ms + KKT pass "
+                                       f"{k2 * 1e3:.0f} ms x3/40; rate scaled by nnz ratio {sc2:.4g}")
+    except Exception as ex:
+        out["torch_coo"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
+    return out
 
 
 def measure_roofline(args, eng, dt, adaptive, world):
@@ -141,7 +174,8 @@ def measure_roofline(args, eng, dt, adaptive, world):
     nnz_kt = int(eng.KT[2].numel())
     b_primal, _ = algorithmic_bytes(nl, eng.m, nnz_kt, sv, si, adaptive)
     _, b_dual = algorithmic_bytes(eng.n, ml, nnz_k, sv, si, adaptive)
-    eng.iterate(1, adaptive)        # (leaves no K'y behind from a restart check: the primal half-step below is the full kernel)
+    N.check(eng.lib.pdlp_primal_half(eng.h, int(adaptive)))   # (leaves no K'y behind from a restart check: the primal half-step
+    N.check(eng.lib.pdlp_dual_half(eng.h, int(adaptive)))     #  timed below is the full kernel)
     ms_primal, ms_dual = time_half_steps(eng, adaptive, args.kernel_reps)
     kfam = lambda t: "k_tiled_fused" if eng.tiles[t] is not None else "k_csr_fused"
     if ms_primal >= ms_dual:
@@ -209,16 +243,33 @@ def main():
             comm.dist.barrier()
         torch.cuda.synchronize()
 
+    period = drv.period
     run(args.warmup)
+    extra = (-drv.tt) % period                 # untimed: up to (and including) the next restart check
+    run(extra)
+    assert drv.tt % period == 0
     fence()
+    checks0, restarts0 = drv.checks, drv.n
     t0 = time.time()
     run(args.steps)
     fence()
     elapsed = time.time() - t0
+    checks_in, restarts_in = drv.checks - checks0, drv.n - restarts0
     if comm is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         comm.dist.all_reduce(tt, op=comm.dist.ReduceOp.MAX)
         elapsed = float(tt)
+    # the cost of one restart check, measured (wall clock, synchronised) on the next whole period(s)
+    run((-drv.tt) % period)
+    drv.check_seconds, c1 = 0.0, drv.checks
+    run(2 * period)
+    check_s = drv.check_seconds / max(1, drv.checks - c1)
+    drv.check_seconds = None
+    if comm is not None:
+        tt = torch.tensor([check_s], dtype=torch.float64, device=dev)
+        comm.dist.all_reduce(tt, op=comm.dist.ReduceOp.MAX)
+        check_s = float(tt)
+    norm_elapsed = elapsed + (args.steps / period - checks_in) * check_s
 
     try:
         roofline = measure_roofline(args, eng, dt, adaptive, world)
@@ -226,19 +277,23 @@ def main():
         roofline = {"bound": "hbm", "error": f"{type(e).__name__}: {e}"[:200]}
 
     out = {
-        "metric": "PDHG iterations/sec", "value": round(args.steps / elapsed, 3), "unit": "iterations/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "metric": "PDHG iterations/sec", "value": round(args.steps / norm_elapsed, 3), "unit": "iterations/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(norm_elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"synthetic random feasible LP {args.n}x{m}, {args.nnz_per_row} nnz/row "
                                f"(density {args.nnz_per_row / args.n:.1e}), gen_lp recipe 'box' seed 0",
-                   "nnz": nnz, "step": f"{args.mode} PDHG iteration incl. 3 KKT evaluations per 40 iterations and restarts",
-                   "primal_weight_update": True, "restarts_in_timed_region": None,
-                   "parallelism": "single GPU" if world == 1 else f"row-block shards of K and K' over {world} GPUs, "
-                                                                  f"all-gather(xbar), all-gather(y) per iteration (RCCL)"},
+                   "nnz": nnz, "step": f"{args.mode} PDHG iteration at the reference's restart cadence (one check = 3 KKT evaluations per "
+                                       f"{period} iterations, + the restart work when one fires), normalised to steps/{period} checks",
+                   "primal_weight_update": True, "kernels": {"K": eng.kernels[0], "K'": eng.kernels[1]},
+                   "parallelism": "single GPU" if world == 1 else
+                   f"row-block shards of K and K' over {world} GPUs, all-gather(xbar), all-gather(y) per iteration "
+                   f"({'RCCL' if comm.backend == 'nccl' else comm.backend + ' (rehearsal, not RCCL)'})"},
+        "timing": {"elapsed_s": round(elapsed, 6), "raw_value": round(args.steps / elapsed, 3), "checks_in_timed_region": checks_in,
+                   "restarts_in_timed_region": restarts_in, "check_ms": round(check_s * 1e3, 3),
+                   "warmup_done": args.warmup + extra, "normalised_elapsed_s": round(norm_elapsed, 6)},
         "roofline": roofline,
         "setup_s": round(setup_s, 1),
     }
-    out["config"]["restarts_in_timed_region"] = drv.n
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         del drv, eng
         torch.cuda.empty_cache()

@@ -152,6 +152,9 @@ int pdlp_dual_half_begin(pdlp_handle h, int adaptive);
 /* what the two calls above will do for K (transpose = 0) or K' (1): out = {first local panel, end of the local panels,
  * panel groups of the local panels, panel groups of the others}; all zero = the product is not split */
 int pdlp_split_info(pdlp_handle h, int transpose, int32_t out[4]);
+/* what pdlp_attach_tiles accepts for this handle: out = {most panel groups (the row-sum scratch has that many slots),
+ * most row blocks (slots of per-workgroup partial sums), most rows per thread, most items per tile} */
+int pdlp_tile_limits(pdlp_handle h, int32_t out[4]);
 /* adaptive rule, part 1: reduce this rank's ||dx||^2, ||dy||^2, dy'K dx into PDLP_BUF_RED[0..2]
  * (all-reduce them across ranks before part 2) -- step.py:91-96 */
 int pdlp_adaptive_reduce(pdlp_handle h);
@@ -235,8 +238,7 @@ int pdlp_csr_row_scale_factors(int dtype, int64_t rows, const int32_t* rowptr, c
 /* val[p] /= norm[row(p)]                      (:52 / :57 on the copy whose rows are being scaled) */
 int pdlp_csr_div_rows(int dtype, int64_t rows, const int32_t* rowptr, void* val, const void* norm, void* stream);
 /* val[p] /= norm_full[colidx[p]]              (the same scaling applied to the transposed copy)   */
-int pdlp_csr_div_cols(int dtype, int64_t rows, const int32_t* rowptr, const int32_t* colidx, void* val,
-                      const void* norm_full, void* stream);
+int pdlp_csr_div_cols(int dtype, int64_t nnz, const int32_t* colidx, void* val, const void* norm_full, void* stream);
 /* elementwise helpers for D /= norm, c*D, l/D ... (:51,:56,:64-67); op: 0 a*=b, 1 a/=b */
 int pdlp_vec_muldiv(int dtype, int64_t len, void* a, const void* b, int op, void* stream);
 /* out = project_lambda_box(g) (helpers.py:3-39): 0 where l = -inf and u = +inf, min(g,0) where only l = -inf,

@@ -19,6 +19,8 @@ Groups:
   G8 mps.npz             mps_to_standard_form on tests/golden/mps/*.mps (util.py:76-268)
   G9 afiro.npz           Netlib afiro: util.mps_to_standard_form + pdlp_algorithm (+ ruiz_precondition)
   G10 infeasibility.npz  detect_infeasibility (enhancements.py:80-161) and pdlp_algorithm(infeasibility_detect=True)
+  G11 fishnet.npz        spectral_cast / sample_points / fishnet / init_PDHG_vars / get_best_pts (spectral_casting.py:5-293)
+  G12 forced_trace.npz   pdlp_algorithm(adaptive=True): state at the start and end of every 40-iteration block
 """
 import contextlib
 import io
@@ -40,6 +42,7 @@ import helpers as ref_helpers             # noqa: E402  (reference)
 import primal_dual_hybrid_gradient as ref_pdhg        # noqa: E402  (reference)
 import primal_dual_hybrid_gradient_step as ref_step   # noqa: E402  (reference)
 import util as ref_util                   # noqa: E402  (reference)
+import spectral_casting as ref_sc         # noqa: E402  (reference)
 
 from torchpdlp_amd.synthetic import csr_to_dense, gen_lp  # noqa: E402
 
@@ -418,8 +421,129 @@ def g10_infeasibility(cases):
     np.savez_compressed(os.path.join(HERE, "infeasibility.npz"), **out)
 
 
+class _TorchProxy:
+    """stands in for the ``torch`` module inside the reference's spectral_casting: records what ``rand`` (breeding
+    weights, :137) and ``argsort`` (survivor order, :238) return; everything else is torch"""
+
+    def __init__(self):
+        self.rands, self.orders, self.gaps = [], [], []
+
+    def __getattr__(self, name):
+        return getattr(torch, name)
+
+    def rand(self, *a, **kw):
+        v = torch.rand(*a, **kw)
+        self.rands.append(v.clone())
+        return v
+
+    def argsort(self, t, *a, **kw):
+        v = torch.argsort(t, *a, **kw)
+        self.gaps.append(t.clone())
+        self.orders.append(v.clone())
+        return v
+
+
+def g11_fishnet(cases):
+    """The fishnet warm start with the global RNG pinned by torch.manual_seed: the points, the radius, eta / omega of
+    init_PDHG_vars, every round's duality gaps and survivor order, the breeding weights and the final (x, y)."""
+    out = {}
+    for name, i, k, seed in (("mixed_400x300", 3, 32, 4321), ("box_200x150", 4, 16, 4322), ("mixed_27x32", 5, 8, 4323)):
+        lp = cases[name]
+        K = csr_to_dense(lp)
+        c, q, l, u = col(lp.c), col(lp.q), col(lp.l), col(lp.u)
+        proxy = _TorchProxy()
+        sigmas = []
+        orig_sn = ref_sc.spectral_norm_estimate_torch
+
+        def rec_sn(*a, **kw):
+            v = orig_sn(*a, **kw)
+            sigmas.append(float(v))
+            return v
+
+        torch.manual_seed(seed)
+        b0_a = torch.randn(lp.n, 1)                      # helpers.py:47 inside sample_points (25 iterations)
+        pts_raw = torch.randn(lp.n, 2 ** i)              # :49
+        b0_b = torch.randn(lp.n, 1)                      # helpers.py:47 inside init_PDHG_vars (50 iterations)
+        ref_sc.torch, ref_sc.spectral_norm_estimate_torch = proxy, rec_sn
+        try:
+            torch.manual_seed(seed)
+            pts, radius = ref_sc.sample_points(K, i, "cpu")
+            pts0 = pts.clone()
+            x, y = ref_sc.fishnet(pts, K, c, q, l, u, lp.m_ineq, 2, k, "cpu")
+            # the same through the top-level entry point: identical by construction
+            torch.manual_seed(seed)
+            x2, y2 = ref_sc.spectral_cast(K, c, q, l, u, lp.m_ineq, k, 2, i, "cpu")
+            assert torch.equal(x, x2) and torch.equal(y, y2)
+            eta, omega, ipi, ini = ref_sc.init_PDHG_vars(K, c, q, l, u)    # (draws again: not comparable, shape only)
+        finally:
+            ref_sc.torch, ref_sc.spectral_norm_estimate_torch = torch, orig_sn
+        nrounds = len(proxy.orders) // 2            # (the second half belongs to the spectral_cast replay)
+        orders = proxy.orders[:nrounds]
+        gaps = proxy.gaps[:nrounds]
+        rands = proxy.rands[:len(proxy.rands) // 2]
+        put(out, name, lp_arrays(lp))
+        put(out, name, dict(i=i, k=k, s=2, seed=seed, b0_radius=b0_a.flatten().numpy(), pts_raw=pts_raw.numpy(),
+                            b0_eta=b0_b.flatten().numpy(), radius=float(radius), sigma25=sigmas[0], sigma50=sigmas[1],
+                            eta=0.9 / sigmas[1], omega=float(torch.linalg.norm(q, 2) / torch.linalg.norm(c, 2)) ** -1,
+                            pts0=pts0.numpy(), x=x.numpy(), y=y.numpy(), nrounds=nrounds, nweights=len(rands)))
+        for r in range(nrounds):
+            put(out, f"{name}/round{r}", dict(gaps=gaps[r].numpy(), order=orders[r].numpy()))
+        for w, v in enumerate(rands):
+            out[f"{name}/weights{w}"] = v.numpy()
+        sep = min(float((torch.sort(g)[0][1:] - torch.sort(g)[0][:-1]).min() / (g.abs().max() + 1e-30)) for g in gaps if g.numel() > 1)
+        print(f"G11 {name}: 2^{i} points, k={k}: rounds={nrounds} weights={len(rands)} radius={float(radius):.5f} "
+              f"eta={0.9 / sigmas[1]:.6f} smallest relative gap separation {sep:.2e}")
+    np.savez_compressed(os.path.join(HERE, "fishnet.npz"), **out)
+
+
+def g12_forced_trace(cases):
+    """pdlp_algorithm(adaptive=True, primal_update=True): the state (x, y, eta, omega, k) going into EVERY step of a few
+    40-iteration blocks of the reference's own run and what the step returned.  A test feeds each recorded state to one
+    step and compares with the recorded successor, so the whole real trajectory (accepted and rejected steps, the phases
+    where eta has grown past the stable range, iterates after restarts to the average) is covered without inheriting
+    the amplification of rounding differences that makes whole blocks incomparable: with the step sizes forced to the
+    reference's, a 1e-5 difference still grows 3x per step while eta sits above eta_bar (measured on box_200x150)."""
+    out = {}
+    for name, blocks in (("mixed_400x300", (0, 3, 9, 20)), ("box_200x150", (0, 2, 7, 12))):
+        lp = cases[name]
+        K = csr_to_dense(lp)
+        calls = []
+        orig = ref_pdhg.adaptive_one_step_pdhg
+
+        def rec(x, y, c, q, Km, l, u, m_ineq, eta, omega, theta, k, j):
+            xi, yi = x.flatten().clone(), y.flatten().clone()
+            r = orig(x, y, c, q, Km, l, u, m_ineq, eta, omega, theta, k, j)
+            calls.append((xi, yi, float(eta), float(omega), int(k), r[0].flatten().clone(), r[1].flatten().clone(),
+                          float(r[2]), float(r[3])))
+            return r
+
+        ref_pdhg.adaptive_one_step_pdhg = rec
+        try:
+            torch.manual_seed(1234)
+            with contextlib.redirect_stdout(io.StringIO()):
+                x, obj, k, n, j, status, _ = ref_pdhg.pdlp_algorithm(
+                    K, lp.m_ineq, col(lp.c), col(lp.q), col(lp.l), col(lp.u), "cpu", max_kkt=100_000, tol=1e-4, verbose=False,
+                    restart_period=40, precondition=False, primal_update=True, adaptive=True)
+        finally:
+            ref_pdhg.adaptive_one_step_pdhg = orig
+        # restarts happen only at multiples of 40 iterations since the last one, so global call indices 0, 40, 80, ...
+        # are exactly the block starts
+        blocks = [b for b in blocks if 40 * b + 40 <= len(calls)]
+        put(out, name, lp_arrays(lp))
+        put(out, name, dict(blocks=np.array(blocks), run_k=k, run_n=n, run_j=j, status=status))
+        for b in blocks:
+            cs = calls[40 * b:40 * b + 40]
+            st = lambda i: np.stack([c_[i].numpy() for c_ in cs]).astype(np.float32)
+            sc = lambda i: np.array([c_[i] for c_ in cs], dtype=np.float64)
+            put(out, f"{name}/block{b}", dict(x_in=st(0), y_in=st(1), eta_in=sc(2), omega=sc(3), k_in=sc(4).astype(np.int64),
+                                             x_out=st(5), y_out=st(6), eta_used=sc(7), eta_hat=sc(8)))
+        rej = sum(1 for b in blocks for c_ in calls[40 * b:40 * b + 40] if c_[7] != c_[2])
+        print(f"G12 {name}: {len(calls)} adaptive calls, blocks {blocks} recorded step by step ({rej} rejected steps), {status} k={k}")
+    np.savez_compressed(os.path.join(HERE, "forced_trace.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"}
+    which = set(sys.argv[1:]) or {"g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"}
     cases = lp_cases()
     if "g1" in which: g1_step_fixed(cases)
     if "g2" in which: g2_step_adaptive(cases)
@@ -431,5 +555,7 @@ if __name__ == "__main__":
     if "g8" in which: g8_mps()
     if "g9" in which: g9_afiro()
     if "g10" in which: g10_infeasibility(cases)
+    if "g11" in which: g11_fishnet(cases)
+    if "g12" in which: g12_forced_trace(cases)
     print("golden fixtures written to", HERE)
 

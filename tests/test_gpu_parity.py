@@ -284,11 +284,25 @@ def test_kkt_vs_golden(golden, name):
 
 
 def test_primal_weight(golden):
+    """primal_weight_update (enhancements.py:73-78): the reference-named operator, and the path the solver takes --
+    pdlp_restart_distance_local (k_sqdiff + k_finalize on the restart point the handle keeps) + the host formula"""
+    from torchpdlp_amd.solver import primal_weight_from_distances
     g = golden("primal_weight.npz")
     for case in g.cases(1):
         r = g.group(case)
         w = tp.primal_weight_update(dev(r["x_prev"]), dev(r["x"]), dev(r["y_prev"]), dev(r["y"]), dev(r["omega"]), 0.5)
         np.testing.assert_allclose(float(w), float(r["omega_new"]), rtol=3e-6)
+        n, m = len(r["x"]), len(r["y"])
+        lp = gen_lp(n, m, min(3, n), seed=1, device=DEV)                      # any LP of that shape: only the vectors matter
+        eng = tp.PdlpEngine.from_full(tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val), lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
+        eng.set_iterate(dev(r["x_prev"]), dev(r["y_prev"]))                   # the restart point (pdhg.py:63-64)
+        eng.buffer(N.BUF_X_CUR).copy_(dev(r["x"]))                            # ... and where the iterations went from there
+        eng.buffer(N.BUF_Y_CUR).copy_(dev(r["y"]))
+        dx2, dy2 = eng.restart_distance()
+        np.testing.assert_allclose(dx2, float(((r["x"].astype(np.float64) - r["x_prev"]) ** 2).sum()), rtol=1e-6, atol=1e-30)
+        np.testing.assert_allclose(dy2, float(((r["y"].astype(np.float64) - r["y_prev"]) ** 2).sum()), rtol=1e-6)
+        w2 = primal_weight_from_distances(dx2, dy2, np.float32(r["omega"]), 0.5, np.float32)
+        np.testing.assert_allclose(float(w2), float(r["omega_new"]), rtol=3e-6)
 
 
 @pytest.mark.parametrize("name", ["mixed_27x32", "mixed_400x300"])
@@ -300,6 +314,36 @@ def test_power_iteration(golden, name, iters):
     s = eng.power_iteration(dev(r["b0"]), iters)
     np.testing.assert_allclose(s, float(r["sigma"]), rtol=5e-5)
     np.testing.assert_allclose(float(tp.spectral_norm_estimate_torch(K, iters, b0=dev(r["b0"]))), float(r["sigma"]), rtol=5e-5)
+
+
+@pytest.mark.parametrize("name", ["mixed_400x300", "box_200x150"])
+def test_forced_trace_adaptive_steps(golden, name):
+    """Every step of recorded 40-iteration blocks of the reference's pdlp_algorithm(adaptive=True, primal_update=True)
+    (tests/golden/forced_trace.npz), each taken from the reference's own state before it: accepted and rejected steps
+    (quirk Q1), step sizes beyond eta_bar, iterates produced by restarts to the average.  Whole blocks cannot be compared:
+    with eta above eta_bar the iteration expands rounding differences 3x per step (gen_golden.g12_forced_trace)."""
+    g = golden("forced_trace.npz")
+    a, K, o, eng = golden_lp(g, name)
+    blocks = [int(b) for b in a["blocks"]]
+    assert len(blocks) >= 3
+    rejected = 0
+    for b in blocks:
+        r = g.group(f"{name}/block{b}")
+        for i in range(40):
+            eng.set_iterate(dev(r["x_in"][i]), dev(r["y_in"][i]))
+            eng.set_step(float(r["eta_in"][i]), float(r["omega"][i]), 1.0, int(r["k_in"][i]) - 1)
+            eng.iterate(1, True)
+            x, y = eng.get_iterate(N.CUR)
+            s = eng.scalars()
+            close(x, r["x_out"][i], 3e-6)
+            close(y, r["y_out"][i], 3e-6)
+            acc_ref = bool(r["eta_used"][i] == r["eta_in"][i])
+            rejected += not acc_ref
+            if abs(s["eta_bar"] - r["eta_in"][i]) > 1e-3 * r["eta_in"][i]:       # (the accept test is a comparison with eta_bar)
+                assert bool(s["accepted"]) == acc_ref, (b, i)
+                np.testing.assert_allclose(s["w_pending"], r["eta_used"][i], rtol=2e-3)
+                np.testing.assert_allclose(s["eta"], r["eta_hat"][i], rtol=2e-3)
+    assert rejected >= 1
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -351,6 +395,12 @@ def test_solve_vs_reference_trace(golden, name, mode):
         nfirst, nk, rt = min(len(trace["restarts"]), len(r["restarts"]), 5), 10, 5e-4
     assert [tuple(v) for v in trace["restarts"][:nfirst]] == [tuple(int(t) for t in v) for v in r["restarts"][:nfirst]]
     np.testing.assert_allclose(trace["kkt"][:nk], r["kkt_trace"][:nk], rtol=rt)
+    # the primal weight after every restart (enhancements.py:73-78), as far as the restart decisions are the reference's
+    if pw:
+        assert len(trace["omega"]) == n and len(r["omega_trace"]) == int(r["n"])
+        np.testing.assert_allclose(trace["omega"][:nfirst], r["omega_trace"][:nfirst], rtol=rt)
+    else:
+        assert trace["omega"] == [] and len(r["omega_trace"]) == 0
     assert abs(obj - float(r["obj"])) <= 2e-3 * (1 + abs(float(r["obj"])))
     if not np.isnan(r["opt_obj"]):
         assert abs(obj - float(r["opt_obj"])) <= 2e-3 * (1 + abs(float(r["opt_obj"])))
@@ -1011,3 +1061,244 @@ def test_random_lps_engine_vs_oracle():
             for key in ("pr", "dr", "gap", "p", "d_adj", "kkt"):
                 assert abs(got[key] - float(ref[key])) <= 20 * tol * scale, (msg, key, got[key], ref[key])
     assert tiled_cases >= 3
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE.json configs at their stated sizes (configs_untested)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tiled", ["0", "1"])
+def test_config1_full_1Mx1M_5nnz_vs_oracle(monkeypatch, tiled):
+    """configs[1] at its full size: synthetic random feasible LP, 1M variables x 1M constraints, 5 non-zeros per row, on one
+    MI355X -- adaptive steps, fixed steps, the KKT pass and the restart machinery against the CPU oracle on the same LP"""
+    monkeypatch.setenv("PDLP_TILED", tiled)
+    n = 1_000_000
+    lp = gen_lp(n, n, 5, seed=0, device=DEV)
+    K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
+    assert K.nnz == 5_000_000
+    eng = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
+    assert eng.kernels == (["csr", "csr"] if tiled == "0" else ["tiled", "tiled"])
+    h = lambda t: t.cpu().numpy()
+    o = orc.OracleLP(lp.m, lp.n, lp.m_ineq, h(K.rowptr), h(K.colidx), h(K.val), h(lp.c), h(lp.q), h(lp.l), h(lp.u),
+                     trans=(h(K.t_rowptr), h(K.t_colidx), h(K.t_val)))
+    orc.set_threads(8)
+    try:
+        g = torch.Generator(device=DEV).manual_seed(5)
+        x0 = torch.minimum(torch.maximum(torch.randn(n, device=DEV, generator=g), lp.l), lp.u)
+        y0 = torch.randn(n, device=DEV, generator=g)
+        y0[:lp.m_ineq].clamp_(min=0)
+        close(eng.spmv(x0, False), o.spmv(h(x0)), 2e-5)
+        close(eng.spmv(y0, True), o.spmv(h(y0), True), 2e-5)
+        sigma = eng.power_iteration(x0, 10)
+        np.testing.assert_allclose(sigma, float(o.power_iter(h(x0), 10)), rtol=1e-4)
+        eta0, omega = np.float32(0.9 / sigma), np.float32(1.7)
+        # adaptive steps (step.py:43-115) with the running average (pdhg.py:107-109), then a restart check's three numbers
+        eng.set_iterate(x0, y0)
+        eng.set_step(float(eta0), float(omega), 1.0, 0)
+        eng.iterate(6, True)
+        xo, yo, eta = h(x0), h(y0), eta0
+        xs, ys, wsum = np.zeros(n), np.zeros(n), 0.0
+        for k in range(1, 7):
+            xo, yo, w, eta, _ = o.step_adaptive(xo, yo, eta, omega, 1.0, k)
+            xs += float(w) * xo
+            ys += float(w) * yo
+            wsum += float(w)
+        x, y = eng.get_iterate(N.CUR)
+        close(x, xo, 5e-5)
+        close(y, yo, 5e-5)
+        np.testing.assert_allclose(eng.scalars()["eta"], float(eta), rtol=2e-4)
+        eng.flush_average()
+        eng.compute_average()
+        close(eng.buffer(N.BUF_X_AVG), xs / wsum, 1e-4)
+        for which, (px, py) in ((N.CUR, (xo, yo)), (N.AVG, ((xs / wsum).astype(np.float32), (ys / wsum).astype(np.float32)))):
+            out, ref = eng.kkt(which, float(omega)), o.kkt(px, py, omega)
+            for key in ("pr", "dr", "p", "d_adj", "kkt"):
+                np.testing.assert_allclose(out[key], float(ref[key]), rtol=2e-4, err_msg=f"{which}:{key}")
+        # fixed steps (step.py:3-40)
+        eng.set_iterate(x0, y0)
+        eng.set_step(float(eta0), float(omega), 1.0, 0)
+        eng.iterate(4, False)
+        xo, yo = h(x0), h(y0)
+        for _ in range(4):
+            xo, yo = o.step_fixed(xo, yo, eta0, omega, 1.0)
+        x, y = eng.get_iterate(N.CUR)
+        close(x, xo, 3e-5)
+        close(y, yo, 3e-5)
+    finally:
+        orc.set_threads(1)
+
+
+def _sample_pairs(K, rows):
+    """(i, j, K[i,j]) of every entry of the sampled rows, plus the value the transposed copy holds for the same (i, j)"""
+    rp, ci, va = K.rowptr.long(), K.colidx.long(), K.val
+    trp, tci, tva = K.t_rowptr.long(), K.t_colidx.long(), K.t_val
+    out = []
+    for i in rows:
+        a, b = int(rp[i]), int(rp[i + 1])
+        for p in range(a, b, max(1, (b - a) // 5)):           # a few entries of the row
+            j = int(ci[p])
+            ta, tb = int(trp[j]), int(trp[j + 1])
+            hit = (tci[ta:tb] == i).nonzero().flatten()
+            assert hit.numel() >= 1
+            out.append((i, j, p, ta + int(hit[0])))
+    return out
+
+
+def test_config4_ruiz_adaptive_10Mx10M_properties(monkeypatch):
+    """configs[4] at its full size: sparse Ruiz (ruiz_precondition, enhancements.py:4-71) + adaptive steps + primal weight on the
+    10M x 10M instance.  Too big for the oracle, so: both CSR copies and the rebuilt tiles carry the same scaled values, they are
+    D_row K D_col, the scaled vectors follow :64-67, the un-scaled KKT pass equals the KKT pass of the un-scaled problem at the
+    un-scaled point (pdhg.py:157-161), and the preconditioned adaptive solve reaches the reference's tolerance on the ORIGINAL LP"""
+    n = 10_000_000
+    lp = gen_lp(n, n, 100, seed=0, device=DEV)
+    K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
+    Ks, c_s, q_s, l_s, u_s, dp, secs = tp.ruiz_precondition(lp.c, K, lp.q, lp.l, lp.u, device=DEV)
+    D_col, D_row = dp[0].reshape(-1), dp[1].reshape(-1)
+    assert Ks.nnz == K.nnz == 1_000_000_000 and torch.equal(Ks.colidx, K.colidx) and torch.equal(Ks.t_colidx, K.t_colidx)
+    # (1) sampled entries: K_s[i,j] = D_row[i] K[i,j] D_col[j] (:51-57), and the transposed copy holds bit for bit the same value
+    rows = [0, 1, 4_999_999, 9_999_999] + [int(v) for v in torch.randint(0, n, (40,), generator=torch.Generator().manual_seed(3))]
+    for i, j, p, pt in _sample_pairs(Ks, rows):
+        v, vt, v0 = float(Ks.val[p]), float(Ks.t_val[pt]), float(K.val[p])
+        assert v == vt, (i, j)
+        np.testing.assert_allclose(v, v0 * float(D_row[i]) * float(D_col[j]), rtol=2e-5)
+        assert float(K.t_val[pt]) == v0
+    # equilibrated: every row and column maximum is close to 1 after 20 sweeps
+    rmax = torch.zeros(n, device=DEV).scatter_reduce_(0, torch.repeat_interleave(torch.arange(n, device=DEV), 100), Ks.val.abs(), "amax")
+    assert 0.7 < float(rmax.min()) and float(rmax.max()) < 1.4
+    # (2) the scaled vectors (:64-67)
+    close(c_s.reshape(-1)[:1000], (lp.c * D_col)[:1000].cpu().numpy(), 1e-6)
+    close(q_s.reshape(-1)[:1000], (lp.q * D_row)[:1000].cpu().numpy(), 1e-6)
+    close(l_s.reshape(-1)[:1000], (lp.l / D_col)[:1000].cpu().numpy(), 1e-6)
+    close(u_s.reshape(-1)[:1000], (lp.u / D_col)[:1000].cpu().numpy(), 1e-6)
+    # (3) engines: scaled problem on the tiled kernels (tiles rebuilt from the scaled CSR), un-scaled problem on the CSR kernels
+    monkeypatch.setenv("PDLP_TILED", "1")
+    es = tp.PdlpEngine.from_full(Ks, c_s, q_s, l_s, u_s, lp.m_ineq, d_col=D_col, d_row=D_row)
+    assert es.kernels == ["tiled", "tiled"]
+    t = es.tiles[0]                                       # one tile's items against the scaled CSR rows it was cut from
+    b, p_ = 7, 11
+    i0, i1 = int(t.tile_ptr[b * t.npanel + p_]), int(t.tile_ptr[b * t.npanel + p_ + 1])
+    r0, r1 = b * t.rows_per_block, min(n, (b + 1) * t.rows_per_block)
+    a0, a1 = int(Ks.rowptr[r0]), int(Ks.rowptr[r1])
+    cc = Ks.colidx[a0:a1].long()
+    sel = (cc >> t.lw) == p_
+    want = torch.sort(Ks.val[a0:a1][sel])[0]
+    got = t.val[i0:i1]
+    got = torch.sort(got[got != 0])[0]
+    assert torch.equal(got, want[want != 0])
+    g = torch.Generator(device=DEV).manual_seed(8)
+    xs = torch.minimum(torch.maximum(torch.randn(n, device=DEV, generator=g), l_s.reshape(-1)), u_s.reshape(-1))
+    ys = torch.randn(n, device=DEV, generator=g)
+    ys[:lp.m_ineq].clamp_(min=0)
+    es.set_iterate(xs, ys)
+    got_u = es.kkt(N.CUR, 1.3, unscaled=True)
+    got_s = es.kkt(N.CUR, 1.3)
+    monkeypatch.setenv("PDLP_TILED", "0")
+    eu = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
+    eu.set_iterate(D_col * xs, D_row * ys)
+    ref_u = eu.kkt(N.CUR, 1.3)
+    for key in ("pr", "dr", "p", "d_adj", "kkt"):
+        np.testing.assert_allclose(got_u[key], ref_u[key], rtol=3e-4, err_msg=key)
+    # the objective is invariant under the scaling (c_s'x_s = c'(D_col x_s)); residuals are not
+    np.testing.assert_allclose(got_s["p"], ref_u["p"], rtol=1e-4)
+    assert abs(got_s["pr"] - ref_u["pr"]) > 1e-3 * ref_u["pr"]
+    del eu
+    # (4) the whole configuration: Ruiz + adaptive step + primal weight, terminating on the un-scaled residuals
+    trace = dict(kkt=[], omega=[], restarts=[])
+    x, obj, k, nr, j, status, total = tp.pdlp_algorithm(Ks, lp.m_ineq, c_s, q_s, l_s, u_s, DEV, tol=1e-4, verbose=False, precondition=True,
+                                                        primal_update=True, adaptive=True, data_precond=dp, seed=0, trace=trace,
+                                                        max_kkt=8000)
+    assert status == "Solved", (status, k, nr, j)
+    assert j == k + (len(trace["kkt"]) - nr) + 2 * nr and len(trace["omega"]) == nr
+    xu = (D_col * x.reshape(-1)).double()
+    assert abs(float((lp.c.double() * xu).sum()) - obj) <= 1e-4 * abs(obj)
+    monkeypatch.setenv("PDLP_TILED", "1")
+    chk = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq)        # the original LP on an independently built engine
+    kx = chk.spmv(xu.float(), False).double() - lp.q.double()
+    viol = torch.cat([kx[:lp.m_ineq].clamp(max=0), kx[lp.m_ineq:]])
+    assert float(viol.norm()) <= 1.2e-4 * (1 + float(lp.q.double().norm()))
+    assert bool((xu >= lp.l.double() - 1e-3).all()) and bool((xu <= lp.u.double() + 1e-3).all())
+
+
+class _OneOfEight:
+    """rank `rank` of 8 for an engine whose full-length buffers the test fills itself (the collectives are no-ops)"""
+    world, backend, group = 8, "fake", None
+
+    def __init__(self, rank):
+        self.rank = rank
+
+    def all_gather(self, full):
+        pass
+
+    def all_reduce_sum(self, t):
+        pass
+
+
+def test_config3_one_eighth_shard_of_10Mx10M(monkeypatch):
+    """configs[3]: the 10M x 10M instance row/column-block sharded over 8 GPUs -- one rank's shard (rank 3: rows 3.75M..5M of K and
+    of K') on one GPU: the split tiled product (local panels first, the others after the all-gather: pdlp_*_half_begin), the
+    unsplit tiled product and the CSR kernel must agree on both half-steps and on the KKT sums"""
+    n, W, rank = 10_000_000, 8, 3
+    lp = gen_lp(n, n, 100, seed=0, device=DEV)
+    K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
+    from torchpdlp_amd.distributed import shard_arrays
+    args = shard_arrays(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq, rank, W)
+    r0, r1 = args["rows"]
+    c0, c1 = args["cols"]
+    assert (r0, r1, c0, c1) == (3_750_000, 5_000_000, 3_750_000, 5_000_000)
+    del K
+    g = torch.Generator(device=DEV).manual_seed(4)
+    xf = torch.minimum(torch.maximum(torch.randn(n, device=DEV, generator=g), lp.l), lp.u)
+    yf = torch.randn(n, device=DEV, generator=g)
+    yf[:lp.m_ineq].clamp_(min=0)
+    xbar_others = xf + 0.01 * torch.randn(n, device=DEV, generator=g)
+
+    def run(tiled, split):
+        monkeypatch.setenv("PDLP_TILED", tiled)
+        eng = tp.PdlpEngine(comm=_OneOfEight(rank), **args)
+        if tiled == "1":
+            assert all(t is not None for t in eng.tiles)
+            info = [eng.split_info(tr) for tr in (0, 1)]
+            assert all(i["local_groups"] >= 1 and i["other_groups"] >= 1 for i in info), info
+            # 1.25M rows: 64 row blocks cannot fill 512 workgroup slots -> the panels of a row block are split into groups
+            assert eng.tiles[0].groups > 1
+        outs = {}
+        for adaptive in (1, 0):
+            eng.set_iterate(xf[c0:c1], yf[r0:r1])
+            eng.buffer(N.BUF_X_CUR).copy_(xf)                   # what the all-gathers would have delivered
+            eng.buffer(N.BUF_Y_CUR).copy_(yf)
+            eng.set_step(0.02, 1.1, 1.0, 0)
+            lib, h = eng.lib, eng.h
+            if split:
+                N.check(lib.pdlp_primal_half_begin(h))
+            N.check(lib.pdlp_primal_half(h, adaptive))
+            xbar = eng.buffer(N.BUF_XBAR)
+            mine = xbar[c0:c1].clone()
+            if split:
+                N.check(lib.pdlp_dual_half_begin(h, adaptive))  # local panels of K against this rank's own block of xbar
+            xbar.copy_(xbar_others)                             # ... the other ranks' blocks arrive
+            xbar[c0:c1] = mine
+            N.check(lib.pdlp_dual_half(h, adaptive))
+            x, y = eng.get_iterate(N.CUR)
+            red = None
+            if adaptive:
+                N.check(lib.pdlp_adaptive_reduce(h))
+                red = eng.buffer(N.BUF_RED)[:3].cpu().numpy().copy()
+            outs[adaptive] = (x.cpu().numpy(), y.cpu().numpy(), mine.cpu().numpy(), red)
+        eng.set_iterate(xf[c0:c1], yf[r0:r1])
+        eng.buffer(N.BUF_X_CUR).copy_(xf)
+        eng.buffer(N.BUF_Y_CUR).copy_(yf)
+        N.check(eng.lib.pdlp_kkt_local(eng.h, N.CUR, 0))
+        outs["kkt"] = eng.buffer(N.BUF_RED)[:6].cpu().numpy().copy()
+        outs["kx"] = eng.spmv(xf, False).cpu().numpy()
+        outs["kty"] = eng.spmv(yf, True).cpu().numpy()
+        return outs
+
+    ref = run("0", False)
+    for tiled, split in (("1", False), ("1", True)):
+        got = run(tiled, split)
+        close(got["kx"], ref["kx"], 2e-5)
+        close(got["kty"], ref["kty"], 2e-5)
+        np.testing.assert_allclose(got["kkt"], ref["kkt"], rtol=1e-5)
+        for adaptive in (1, 0):
+            for a_, b_ in zip(got[adaptive][:3], ref[adaptive][:3]):
+                close(a_, b_, 2e-5)
+        np.testing.assert_allclose(got[1][3], ref[1][3], rtol=1e-5)

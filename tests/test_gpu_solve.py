@@ -162,3 +162,51 @@ def test_fishnet_population_path_equals_point_by_point(golden):
             for mv in (True, False)]
     np.testing.assert_allclose(outs[0][0].cpu().numpy(), outs[1][0].cpu().numpy(), rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(outs[0][1].cpu().numpy(), outs[1][1].cpu().numpy(), rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("name", ["mixed_400x300", "box_200x150", "mixed_27x32"])
+@pytest.mark.parametrize("multi_vector", [True, False])
+def test_fishnet_vs_reference_golden(golden, name, multi_vector):
+    """spectral_cast (spectral_casting.py:5-29) = sample_points (:32-63) + fishnet (:65-159) with get_best_pts (:191-252),
+    init_PDHG_vars (:161-189) and PDHG_step (:254-293), against the reference run recorded in tests/golden/fishnet.npz: a CPU
+    generator with the recorded seed replays the reference's random stream draw for draw (power-iteration starts, points,
+    breeding weights), so points, radius, eta, every round's gaps and survivor order, and the final (x, y) are comparable"""
+    g = golden("fishnet.npz")
+    a, r = g.group(name), g.group(name)
+    t = lambda v, dt=torch.float32: torch.tensor(np.asarray(v), dtype=dt, device="cuda:0")
+    K = tp.CsrPair(int(a["m"]), int(a["n"]), t(a["rowptr"], torch.int32), t(a["colidx"], torch.int32), t(a["val"]))
+    eng = tp.PdlpEngine.from_full(K, t(a["c"]), t(a["q"]), t(a["l"]), t(a["u"]), int(a["m_ineq"]))
+    gen = torch.Generator().manual_seed(int(r["seed"]))
+    pts, radius = tp.sample_points(eng, int(r["i"]), gen)
+    np.testing.assert_allclose(radius, float(r["radius"]), rtol=5e-5)
+    np.testing.assert_allclose(pts.numpy(), r["pts0"], rtol=3e-5, atol=3e-5 * float(np.abs(r["pts0"]).max()))
+    trace = []
+    x, y = tp.fishnet(eng, torch.tensor(r["pts0"]), s=int(r["s"]), k=int(r["k"]), generator=gen, multi_vector=multi_vector, trace=trace)
+    assert len(trace) == int(r["nrounds"])
+    for rnd, (gaps, order) in enumerate(trace):
+        ref = g.group(f"{name}/round{rnd}")
+        scale = float(np.max(np.abs(ref["gaps"]))) + 1e-30
+        np.testing.assert_allclose(gaps, ref["gaps"], rtol=3e-4, atol=3e-4 * scale, err_msg=f"round {rnd}")
+        assert list(order) == [int(v) for v in ref["order"]], f"survivor order, round {rnd}"
+    np.testing.assert_allclose(x.cpu().numpy(), r["x"], rtol=3e-4, atol=3e-4 * float(np.abs(r["x"]).max()))
+    np.testing.assert_allclose(y.cpu().numpy(), r["y"], rtol=3e-4, atol=3e-4 * float(np.abs(r["y"]).max()))
+    # the generator now stands where the reference's global RNG stood at the end: every draw was replayed
+    assert gen.get_state().equal(_state_after(int(r["seed"]), a, r, g, name))
+    # the top-level entry point does the same from the seed alone
+    if multi_vector:
+        x2, y2 = tp.spectral_cast(K, t(a["c"]), t(a["q"]), t(a["l"]), t(a["u"]), int(a["m_ineq"]), int(r["k"]), 2, int(r["i"]), "cuda:0",
+                                  generator=torch.Generator().manual_seed(int(r["seed"])))
+        np.testing.assert_allclose(x2.cpu().numpy(), r["x"], rtol=3e-4, atol=3e-4 * float(np.abs(r["x"]).max()))
+        np.testing.assert_allclose(y2.cpu().numpy(), r["y"], rtol=3e-4, atol=3e-4 * float(np.abs(r["y"]).max()))
+
+
+def _state_after(seed, a, r, g, name):
+    """the CPU generator's state after the reference's sequence of draws (shapes as recorded)"""
+    gen = torch.Generator().manual_seed(seed)
+    n = int(a["n"])
+    torch.randn(n, generator=gen)
+    torch.randn(n, 2 ** int(r["i"]), generator=gen)
+    torch.randn(n, generator=gen)
+    for w in range(int(r["nweights"])):
+        torch.rand(len(g[f"{name}/weights{w}"]), generator=gen)
+    return gen.get_state()

@@ -182,6 +182,12 @@ def test_solve_trace(golden, name, mode):
         nfirst, nk, rt = min(len(trace["restarts"]), len(r["restarts"]), 6), 12, 2e-4
     assert [tuple(v) for v in trace["restarts"][:nfirst]] == [tuple(v) for v in r["restarts"][:nfirst]]
     np.testing.assert_allclose(trace["kkt"][:nk], r["kkt_trace"][:nk], rtol=rt)
+    # primal weight after every restart (enhancements.py:73-78), as far as the restart decisions are the reference's
+    if pw:
+        assert len(trace["omega"]) == n and len(r["omega_trace"]) == int(r["n"])
+        np.testing.assert_allclose(trace["omega"][:nfirst], r["omega_trace"][:nfirst], rtol=rt)
+    else:
+        assert len(trace["omega"]) == 0 and len(r["omega_trace"]) == 0
     if not adaptive and not pw and name != "mixed_300x400_alleq":   # (that one parts ways at restart 9 of 12)
         assert (k, n, j) == (int(r["k"]), int(r["n"]), int(r["j"]))
     # same answer to the solver's own tolerance
@@ -242,3 +248,119 @@ def test_solve_with_infeasibility_detection_follows_the_reference(golden, name, 
         assert abs(obj - float(r["obj"])) <= 5e-3 * (1 + abs(float(r["obj"])))
     if st in ("DUAL_INFEASIBLE", "PRIMAL_INFEASIBLE"):
         assert j == 2 * k - 1 + 3 * ((k - 1) // 40) + 2 * n      # a pass per step, a detector pass from k = 2, restart checks before k
+
+
+# ---------------------------------------------------------------------------------------------------
+# fishnet warm start (spectral_casting.py:5-293), pinned by tests/golden/fishnet.npz
+# ---------------------------------------------------------------------------------------------------
+FISHNET_CASES = ["mixed_400x300", "box_200x150", "mixed_27x32"]
+
+
+def fishnet_weights(g, name):
+    r = g.group(name)
+    return [g[f"{name}/weights{w}"] for w in range(int(r["nweights"]))]
+
+
+@pytest.mark.parametrize("name", FISHNET_CASES)
+def test_fishnet_sample_points_and_init(golden, name):
+    """sample_points (:32-63) and init_PDHG_vars (:161-189) with the reference's random draws replayed"""
+    g = golden("fishnet.npz")
+    lp = lp_from(g, name)
+    r = g.group(name)
+    pts, radius = orc.sample_points(lp, r["pts_raw"], r["b0_radius"], 25)
+    np.testing.assert_allclose(radius, r["radius"], rtol=5e-5)
+    np.testing.assert_allclose(radius, r["sigma25"], rtol=5e-5)
+    assert pts.shape == (lp.n, 2 ** int(r["i"]))
+    close(pts, r["pts0"], 2e-5)
+    np.testing.assert_allclose(0.9 / lp.power_iter(r["b0_eta"], 50), r["eta"], rtol=5e-5)          # :180
+    qn, cn = np.linalg.norm(lp.q.astype(np.float64)), np.linalg.norm(lp.c.astype(np.float64))
+    np.testing.assert_allclose(cn / qn, r["omega"], rtol=1e-6)                                   # :181
+
+
+@pytest.mark.parametrize("name", FISHNET_CASES)
+def test_fishnet_vs_reference(golden, name):
+    """fishnet (:65-159) / get_best_pts (:191-252) / PDHG_step (:254-293): same population, same breeding weights ->
+    the reference's duality gaps, survivor order in every round, and final point"""
+    g = golden("fishnet.npz")
+    lp = lp_from(g, name)
+    r = g.group(name)
+    trace = []
+    x, y = orc.fishnet(lp, r["pts0"], s=int(r["s"]), k=int(r["k"]), eta=np.float32(r["eta"]),
+                       weights=iter(fishnet_weights(g, name)), trace=trace)
+    assert len(trace) == int(r["nrounds"])
+    for rnd, (gaps, order) in enumerate(trace):
+        ref = g.group(f"{name}/round{rnd}")
+        scale = np.max(np.abs(ref["gaps"])) + 1e-30
+        np.testing.assert_allclose(gaps, ref["gaps"], rtol=2e-4, atol=2e-4 * scale, err_msg=f"round {rnd}")
+        assert list(order) == list(ref["order"]), f"survivor order, round {rnd}"
+    close(x, r["x"], 2e-4)
+    close(y, r["y"], 2e-4)
+
+
+# ---------------------------------------------------------------------------------------------------
+# every step of blocks of the reference's own adaptive run (tests/golden/forced_trace.npz)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["mixed_400x300", "box_200x150"])
+def test_forced_trace_adaptive_steps(golden, name):
+    """Each step of recorded 40-iteration blocks of pdlp_algorithm(adaptive=True, primal_update=True), taken from the
+    reference's own state before that step: accepted and rejected steps (quirk Q1), eta beyond eta_bar, iterates that
+    restarts to the average produced.  (Whole blocks cannot be compared: see gen_golden.g12_forced_trace.)"""
+    g = golden("forced_trace.npz")
+    lp = lp_from(g, name)
+    blocks = [int(b) for b in g.group(name)["blocks"]]
+    assert len(blocks) >= 3
+    rejected = 0
+    for b in blocks:
+        r = g.group(f"{name}/block{b}")
+        for i in range(40):
+            x, y, w, eh, info = lp.step_adaptive(r["x_in"][i], r["y_in"][i], np.float32(r["eta_in"][i]), np.float32(r["omega"][i]),
+                                                 1.0, int(r["k_in"][i]))
+            close(x, r["x_out"][i], 2e-6)
+            close(y, r["y_out"][i], 2e-6)
+            acc_ref = r["eta_used"][i] == r["eta_in"][i]
+            # the accept test compares eta with eta_bar (step.py:110): the few steps with both within rounding may differ
+            if abs(float(info["eta_bar"]) - r["eta_in"][i]) > 1e-4 * r["eta_in"][i]:
+                assert info["accepted"] == acc_ref, (b, i)
+                np.testing.assert_allclose(w, r["eta_used"][i], rtol=1e-3)
+                np.testing.assert_allclose(eh, r["eta_hat"][i], rtol=1e-3)
+            rejected += not acc_ref
+            if i < 39:       # the loop feeds the step's outputs to the next step unchanged (pdhg.py:80-112)
+                assert np.array_equal(r["x_out"][i], r["x_in"][i + 1]) and r["eta_hat"][i] == r["eta_in"][i + 1]
+    assert rejected >= 1
+
+
+# ---------------------------------------------------------------------------------------------------
+# the reference-faithful torch-COO restatement (bench.py's second CPU baseline flavour), pinned like the C oracle
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["mixed_400x300", "box_200x150"])
+def test_torch_coo_restatement_vs_reference(golden, name):
+    import torch
+    from oracle.torch_coo import TorchCooLP
+    torch.set_num_threads(1)
+    g = golden("step_fixed.npz")
+    a = g.group(name)
+    lp = TorchCooLP(a["m"], a["n"], a["m_ineq"], a["rowptr"], a["colidx"], a["val"], a["c"], a["q"], a["l"], a["u"])
+    col = lambda v: torch.as_tensor(np.asarray(v), dtype=torch.float32).reshape(-1, 1).clone()
+    x, y = col(a["x0"]), col(a["y0"])
+    eta, omega = torch.tensor(np.float32(a["eta"])), torch.tensor(np.float32(a["omega"]))
+    for it in range(1, 41):
+        x, y = lp.step_fixed(x, y, eta, omega, 1.0)
+        if it in (1, 2, 40):
+            close(x.flatten().numpy(), a[f"x{it}"], 2e-6 * it)
+            close(y.flatten().numpy(), a[f"y{it}"], 2e-6 * it)
+    g2 = golden("step_adaptive.npz")
+    a2 = g2.group(name)
+    for tag in ("accept", "reject", "late"):
+        r = g2.group(f"{name}/{tag}")
+        x1, y1, used, nxt = lp.step_adaptive(col(a2["x0"]), col(a2["y0"]), torch.tensor(np.float32(r["eta_in"])),
+                                             torch.tensor(np.float32(a2["omega"])), 1.0, int(r["k"]))
+        close(x1.flatten().numpy(), r["x1"], 2e-6)
+        close(y1.flatten().numpy(), r["y1"], 2e-6)
+        np.testing.assert_allclose(float(used), r["eta_used"], rtol=2e-5)
+        np.testing.assert_allclose(float(nxt), r["eta_hat"], rtol=2e-5)
+    g3 = golden("kkt.npz")
+    for tag in ("rand", "feas"):
+        r = g3.group(f"{name}/{tag}")
+        out = lp.kkt(col(r["x"]), col(r["y"]), torch.tensor(np.float32(r["omega"])))
+        for key in ("pr", "dr", "gap", "p", "d_adj", "kkt"):
+            np.testing.assert_allclose(float(out[key]), float(r[key][0]), rtol=2e-5, atol=2e-5 * (1 + abs(float(r["p"][0]))))

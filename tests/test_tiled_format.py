@@ -5,6 +5,7 @@ import pytest
 import scipy.sparse as sp
 import torch
 
+from torchpdlp_amd import tiled as T
 from torchpdlp_amd.tiled import NT, build_tiles, choose_rpt, choose_shape, emulate_spmv, normalize_groups, tile_row_counts
 
 
@@ -112,3 +113,20 @@ def test_panel_width_adapts_to_long_rows():
     x = torch.from_numpy(np.random.default_rng(1).standard_normal(n).astype(np.float32))
     ref = sp.csr_matrix((va.numpy().astype(np.float64), ci.numpy(), rp.numpy()), shape=(m, n)) @ x.numpy().astype(np.float64)
     np.testing.assert_allclose(emulate_spmv(t, x).numpy(), ref, rtol=1e-12, atol=1e-12)
+
+
+def test_chosen_groups_fit_the_rowsum_scratch():
+    """the library sizes its row-sum scratch by ``rowsum_groups(rows)`` (1 group above ~10.5M rows) and rejects
+    tiles with more panel groups; the shape chooser must be given, and respect, that limit for every size"""
+    for rows in (200_000, 1_250_000, 5_000_000, 10_000_000, 10_485_760, 10_485_761, 10_600_000, 12_000_000, 15_000_000,
+                 20_000_000, 30_000_000):
+        lim = T.rowsum_groups(rows)
+        assert lim == (16 if rows <= 512 * 40 * 128 else 8 if rows <= 512 * 40 * 512 else 1)
+        for per_row in (5, 20, 50):
+            for rpt_max, cap in ((T.RPT_MAX, T.CAP), (T.RPT_MAX_F64, T.CAP_F64)):
+                for cols in (rows, 4 * rows, rows // 4):
+                    lw = T.choose_lw(rows, rows * per_row, cols)
+                    rpt, groups = T.choose_shape(rows, rows * per_row, cols, lw, cap, max_groups=min(8, lim), rpt_max=rpt_max)
+                    assert 1 <= groups <= lim and 1 <= rpt <= rpt_max
+                    P = max(1, (cols + (1 << lw) - 1) >> lw)
+                    assert T.normalize_groups(groups, P, min(8, lim)) == groups

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PDLP_LIB", os.path.join(_HERE, "libpdlp_hip.so"))   # PDLP_LIB: profiling/ablation builds
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 PDLP_F32, PDLP_F64 = 0, 1
 CUR, AVG, PREV = 0, 1, 2
 (BUF_X_CUR, BUF_X_PREV, BUF_XBAR, BUF_X_AVG, BUF_Y_CUR, BUF_Y_PREV, BUF_Y_AVG, BUF_RED, BUF_X_SUM, BUF_Y_SUM,
@@ -58,6 +58,7 @@ SIGNATURES = {
     "pdlp_primal_half_begin": (_I, [_H]),
     "pdlp_dual_half_begin": (_I, [_H, _I]),
     "pdlp_split_info": (_I, [_H, _I, C.POINTER(C.c_int32)]),
+    "pdlp_tile_limits": (_I, [_H, C.POINTER(C.c_int32)]),
     "pdlp_adaptive_reduce": (_I, [_H]),
     "pdlp_adaptive_update": (_I, [_H]),
     "pdlp_iterate": (_I, [_H, _I, _I]),
@@ -80,7 +81,7 @@ SIGNATURES = {
     "pdlp_power_iteration": (_I, [_H, _P, _I, _P, _P, C.POINTER(_D)]),
     "pdlp_csr_row_scale_factors": (_I, [_I, _I64, _P, _P, _D, _P, _P]),
     "pdlp_csr_div_rows": (_I, [_I, _I64, _P, _P, _P, _P]),
-    "pdlp_csr_div_cols": (_I, [_I, _I64, _P, _P, _P, _P, _P]),
+    "pdlp_csr_div_cols": (_I, [_I, _I64, _P, _P, _P, _P]),
     "pdlp_vec_muldiv": (_I, [_I, _I64, _P, _P, _I, _P]),
     "pdlp_vec_project_lambda": (_I, [_I, _I64, _P, _P, _P, _P, _P]),
     "pdlp_vec_max_dev_from_one": (_I, [_I, _I64, _P, _P, C.POINTER(_D), _P]),

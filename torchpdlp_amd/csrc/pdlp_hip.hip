@@ -174,6 +174,7 @@ struct pdlp_solver {
     void* rowsum;                 // row sums of the tiled kernel on their way to the epilogue: [groups][rs_stride]
     int64_t rs_stride;            // rows + one row block
     int rs_groups;                // panel groups the scratch has room for
+    int64_t part_blocks;          // workgroups partA / partB have room for
     int last_gridA, last_gridB;   // grids of the last primal / dual launch (adaptive reduce)
     bool use_split;               // set by the half-step that may consume a pending local-panel product
     // optional (PDLP_GRAPH=1): pdlp_iterate replays two captured iterations (the buffer roles return after two) as one
@@ -657,7 +658,7 @@ int64_t layout(const pdlp_problem* p, int64_t nnzK, int64_t nnzKT, int64_t* offs
     offs[k++] = c.take(nl * es);                                  // 9     x_last
     offs[k++] = c.take(ml * es);                                  // 10    y_last
     for (int i = 0; i < 3; ++i) offs[k++] = c.take(ml * es);     // 11..13 kx caches
-    const int64_t pgrid = MAX_GRID + LONG_GRID + (nl > ml ? nl : ml) / (TNT * 2) + 1;  // CSR grid (+ long rows), or one workgroup per >= 512 rows (tiled)
+    const int64_t pgrid = MAX_GRID + LONG_GRID + (nl > ml ? nl : ml) / TNT + 2;  // CSR grid (+ long rows), or one workgroup per >= 512 rows (tiled, rpt >= 1)
     offs[k++] = c.take(pgrid * NACC * 8);                         // 14    partA
     offs[k++] = c.take(pgrid * NACC * 8);                         // 15    partB
     offs[k++] = c.take(PDLP_NRED * 8);                            // 16    red
@@ -681,10 +682,15 @@ int64_t layout(const pdlp_problem* p, int64_t nnzK, int64_t nnzKT, int64_t* offs
     return c.off;
 }
 
-int read_last_rowptr(const int32_t* rp, int64_t rows, int64_t* nnz)
+int read_last_rowptr(const int32_t* rp, int64_t rows, int64_t* nnz, hipStream_t stream)
 {
+    // the arrays may just have been produced by kernels on the caller's stream (a non-blocking stream is not ordered
+    // against the null stream's copy): read on that stream and wait
     int32_t v = 0;
-    if (rows > 0) HIP_TRY(hipMemcpy(&v, rp + rows, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (rows > 0) {
+        HIP_TRY(hipMemcpyAsync(&v, rp + rows, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
     *nnz = v;
     return PDLP_OK;
 }
@@ -696,7 +702,7 @@ int read_last_rowptr(const int32_t* rp, int64_t rows, int64_t* nnz)
 // ================================================================================================
 extern "C" {
 
-int pdlp_abi_version(void) { return 3; }   // 3: infeasibility detection entry points, PDLP_BUF_DX/DY
+int pdlp_abi_version(void) { return 4; }   // 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
 
 const char* pdlp_strerror(int code)
 {
@@ -717,8 +723,8 @@ int pdlp_workspace_bytes(const pdlp_problem* p, int64_t* bytes)
     if (rc != PDLP_OK || !bytes) return PDLP_ERR_INVALID;
     HIP_TRY(hipSetDevice(p->device));
     int64_t nnzK = 0, nnzKT = 0, offs[40];
-    if ((rc = read_last_rowptr(p->K_rowptr, p->row1 - p->row0, &nnzK)) != PDLP_OK) return rc;
-    if ((rc = read_last_rowptr(p->KT_rowptr, p->col1 - p->col0, &nnzKT)) != PDLP_OK) return rc;
+    if ((rc = read_last_rowptr(p->K_rowptr, p->row1 - p->row0, &nnzK, (hipStream_t)p->stream)) != PDLP_OK) return rc;
+    if ((rc = read_last_rowptr(p->KT_rowptr, p->col1 - p->col0, &nnzKT, (hipStream_t)p->stream)) != PDLP_OK) return rc;
     *bytes = layout(p, nnzK, nnzKT, offs);
     return PDLP_OK;
 }
@@ -730,8 +736,10 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     HIP_TRY(hipSetDevice(p->device));
     const int64_t nl = p->col1 - p->col0, ml = p->row1 - p->row0;
     std::vector<int32_t> rpK((size_t)ml + 1, 0), rpKT((size_t)nl + 1, 0);
-    if (ml > 0) HIP_TRY(hipMemcpy(rpK.data(), p->K_rowptr, (size_t)(ml + 1) * 4, hipMemcpyDeviceToHost));
-    if (nl > 0) HIP_TRY(hipMemcpy(rpKT.data(), p->KT_rowptr, (size_t)(nl + 1) * 4, hipMemcpyDeviceToHost));
+    hipStream_t pstream = (hipStream_t)p->stream;
+    if (ml > 0) HIP_TRY(hipMemcpyAsync(rpK.data(), p->K_rowptr, (size_t)(ml + 1) * 4, hipMemcpyDeviceToHost, pstream));
+    if (nl > 0) HIP_TRY(hipMemcpyAsync(rpKT.data(), p->KT_rowptr, (size_t)(nl + 1) * 4, hipMemcpyDeviceToHost, pstream));
+    HIP_TRY(hipStreamSynchronize(pstream));     // (ordered behind whatever produced the arrays on that stream)
     if (rpK[0] != 0 || rpKT[0] != 0) return PDLP_ERR_INVALID;
     int64_t offs[40];
     const int64_t need = layout(p, rpK[ml], rpKT[nl], offs);
@@ -763,6 +771,7 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     h->no_kty_reuse = std::getenv("PDLP_NO_KTY_REUSE") != nullptr;
     h->rs_stride = (nl > ml ? nl : ml) + (int64_t)TNT * TRPT_MAX_ANY;
     h->rs_groups = (int)rowsum_groups(nl > ml ? nl : ml);
+    h->part_blocks = MAX_GRID + LONG_GRID + (nl > ml ? nl : ml) / TNT + 2;
     h->kx_valid = false; h->cand_valid[0] = h->cand_valid[1] = false;
     h->last_gridA = h->last_gridB = 0;
     for (auto& g : h->graphs) g.valid = false;
@@ -785,12 +794,14 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     build_schedule_host(rpK, ml, sched);
     h->sK.nblk = ml > 0 ? (int)sched.size() / 2 - 1 : 0;
     h->sK.grid = h->sK.nblk < MAX_GRID ? h->sK.nblk : MAX_GRID;
-    rc = hipMemcpy(h->sK.blk, sched.data(), sched.size() * 4, hipMemcpyHostToDevice) == hipSuccess ? PDLP_OK : PDLP_ERR_HIP_BASE - 1;
+    auto upload = [&](void* dst, const void* src, size_t bytes) {      // ordered with later work on the caller's stream
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess;
+    };
+    rc = upload(h->sK.blk, sched.data(), sched.size() * 4) ? PDLP_OK : PDLP_ERR_HIP_BASE - 1;
     build_schedule_host(rpKT, nl, sched);
     h->sKT.nblk = nl > 0 ? (int)sched.size() / 2 - 1 : 0;
     h->sKT.grid = h->sKT.nblk < MAX_GRID ? h->sKT.nblk : MAX_GRID;
-    if (rc == PDLP_OK && hipMemcpy(h->sKT.blk, sched.data(), sched.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
-        rc = PDLP_ERR_HIP_BASE - 1;
+    if (rc == PDLP_OK && !upload(h->sKT.blk, sched.data(), sched.size() * 4)) rc = PDLP_ERR_HIP_BASE - 1;
     // rows longer than NNZ_CAP
     for (int t = 0; t < 2 && rc == PDLP_OK; ++t) {
         Schedule& sc = t == 0 ? h->sK : h->sKT;
@@ -803,9 +814,8 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
         const int64_t work = (int64_t)sc.nblk + sc.nchunks;
         sc.grid = (int)(work < MAX_GRID ? work : MAX_GRID);
         if (sc.nlong > 0) {
-            if (hipMemcpy(sc.lch, lch.data(), lch.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-                hipMemcpy(sc.lrow, lrow.data(), lrow.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-                hipMemcpy(sc.lptr, lptr.data(), lptr.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+            if (!upload(sc.lch, lch.data(), lch.size() * 4) || !upload(sc.lrow, lrow.data(), lrow.size() * 4) ||
+                !upload(sc.lptr, lptr.data(), lptr.size() * 4))
                 rc = PDLP_ERR_HIP_BASE - 1;
         }
     }
@@ -862,6 +872,7 @@ int pdlp_attach_tiles(pdlp_handle h, int transpose, const pdlp_tiles* t)
     const int64_t rb = (int64_t)TNT * t->rpt;
     if (t->nblk != (int)((rows + rb - 1) / rb) || t->npanel < 1) return PDLP_ERR_INVALID;
     if (t->groups < 1 || t->groups > h->rs_groups || t->groups > t->npanel) return PDLP_ERR_INVALID;
+    if (t->nblk > h->part_blocks) return PDLP_ERR_INVALID;             // one slot of partial sums per workgroup
     const int ppg = (t->npanel + t->groups - 1) / t->groups;
     if ((t->groups - 1) * ppg >= t->npanel) return PDLP_ERR_INVALID;     // every group must own at least one panel
     if (!t->idx || !t->val || !t->tile_ptr || !t->cnt) return PDLP_ERR_INVALID;
@@ -957,6 +968,16 @@ int pdlp_split_info(pdlp_handle h, int transpose, int32_t out[4])
     if (!h || !out) return PDLP_ERR_INVALID;
     const Schedule& s = transpose ? h->sKT : h->sK;
     out[0] = s.loc_pa; out[1] = s.loc_pb; out[2] = s.slotsA; out[3] = s.slotsB;
+    return PDLP_OK;
+}
+
+int pdlp_tile_limits(pdlp_handle h, int32_t out[4])
+{
+    if (!h || !out) return PDLP_ERR_INVALID;
+    out[0] = h->rs_groups;
+    out[1] = (int32_t)(h->part_blocks > INT32_MAX ? INT32_MAX : h->part_blocks);
+    out[2] = h->p.dtype == PDLP_F32 ? TileCfg<float>::RPT_MAX : TileCfg<double>::RPT_MAX;
+    out[3] = h->p.dtype == PDLP_F32 ? TileCfg<float>::CAP : TileCfg<double>::CAP;
     return PDLP_OK;
 }
 
@@ -1247,19 +1268,16 @@ int pdlp_csr_div_rows(int dtype, int64_t rows, const int32_t* rowptr, void* val,
     return PDLP_OK;
 }
 
-int pdlp_csr_div_cols(int dtype, int64_t rows, const int32_t* rowptr, const int32_t* colidx, void* val, const void* norm_full, void* stream)
+int pdlp_csr_div_cols(int dtype, int64_t nnz, const int32_t* colidx, void* val, const void* norm_full, void* stream)
 {
-    if (rows < 0 || (dtype != PDLP_F32 && dtype != PDLP_F64)) return PDLP_ERR_INVALID;
-    if (rows == 0) return PDLP_OK;
-    int32_t nnz = 0;
-    HIP_TRY(hipMemcpy(&nnz, rowptr + rows, 4, hipMemcpyDeviceToHost));
+    if (nnz < 0 || (dtype != PDLP_F32 && dtype != PDLP_F64)) return PDLP_ERR_INVALID;
     if (nnz == 0) return PDLP_OK;
     const int g = grid_for(nnz);
     if (dtype == PDLP_F32)
-        hipLaunchKernelGGL(k_div_cols<float>, dim3(g), dim3(BLOCK), 0, (hipStream_t)stream, (int64_t)nnz, colidx, (float*)val,
+        hipLaunchKernelGGL(k_div_cols<float>, dim3(g), dim3(BLOCK), 0, (hipStream_t)stream, nnz, colidx, (float*)val,
                            (const float*)norm_full);
     else
-        hipLaunchKernelGGL(k_div_cols<double>, dim3(g), dim3(BLOCK), 0, (hipStream_t)stream, (int64_t)nnz, colidx, (double*)val,
+        hipLaunchKernelGGL(k_div_cols<double>, dim3(g), dim3(BLOCK), 0, (hipStream_t)stream, nnz, colidx, (double*)val,
                            (const double*)norm_full);
     HIP_TRY(hipGetLastError());
     return PDLP_OK;

@@ -98,30 +98,47 @@ class PdlpEngine:
         N.check(self.lib.pdlp_create(C.byref(self.h), C.byref(self.prob), self.workspace.data_ptr() + self._ws_off,
                                      nbytes.value), "pdlp_create")
         self._views = {}
+        self._mv_work = {}
         self.tiles = [None, None]
+        self.kernels = ["csr", "csr"]
         self._maybe_attach_tiles()
 
     # ---- panel-tiled matrix copies (fast path for wide gathered vectors) -------------------------------
+    def tile_limits(self) -> dict:
+        """what ``pdlp_attach_tiles`` accepts on this handle (the row-sum scratch and the partial-sum slots are sized at creation)"""
+        out = (C.c_int32 * 4)()
+        N.check(self.lib.pdlp_tile_limits(self.h, out), "pdlp_tile_limits")
+        return dict(max_groups=out[0], max_blocks=out[1], rpt_max=out[2], cap=out[3])
+
     def _maybe_attach_tiles(self):
-        """PDLP_TILED=0 never, =1 whenever the matrix is eligible, auto (default): for matrices with >= 2^20 non-zeros
-        whose gathered vector has >= 2^16 entries build the tiles, time both kernels on this device and keep the
-        faster one (measured: 1M x 1M with 100 per row 3.3x faster tiled, 500k x 500k with 20 per row 1.35x; with
-        5 per row the CSR kernel stays ahead)."""
+        """Which kernel multiplies each matrix -- decided from the shape alone, so a run (and every rank of a sharded
+        one) always takes the same kernel and therefore the same summation order:
+        ``PDLP_TILED=0`` never tiles, ``=1`` tiles whenever the matrix is eligible, ``auto`` (default) tiles matrices with
+        >= 2^20 non-zeros, >= 10 per row on average and a gathered vector of >= 2^16 entries (measured: 1M x 1M with 100
+        per row 3.3x faster tiled, 500k x 500k with 20 per row 1.35x; with 5 per row the CSR kernel is ahead),
+        ``=time`` builds the tiles for every candidate, times both kernels on this device and keeps the faster one
+        (not reproducible run to run; tuning only).  ``self.kernels`` records the choice per matrix."""
         mode = os.environ.get("PDLP_TILED", "auto")
+        self.kernels = ["csr", "csr"]
         if mode == "0":
             return
+        lim = self.tile_limits()
         for transpose, (rp, ci, va), rows, cols in ((0, self.K, self.ml, self.n), (1, self.KT, self.nl, self.m)):
-            if rows == 0 or (mode != "1" and (cols < (1 << 16) or int(va.numel()) < (1 << 20))):
+            nnz = int(va.numel())
+            if rows == 0 or (mode != "1" and (cols < (1 << 16) or nnz < (1 << 20))):
+                continue
+            if mode == "auto" and nnz < 10 * rows:
                 continue
             knob = lambda name: int(os.environ[name]) if os.environ.get(name) else None      # tuning experiments
             t = _tiled.build_tiles(rp, ci, va, rows, cols, lw=knob("PDLP_TILE_LW"), rpt=knob("PDLP_TILE_RPT"),
-                                   groups=knob("PDLP_TILE_GROUPS"))
-            if t is None:
+                                   groups=knob("PDLP_TILE_GROUPS"), max_groups=lim["max_groups"])
+            if t is None or t.nblk > lim["max_blocks"]:
                 continue
-            if mode == "1":
+            if mode != "time":
                 self.attach_tiles(transpose, t)
                 continue
-            vin = torch.zeros(cols, dtype=self.dtype, device=self.device)
+            g = torch.Generator(device=self.device).manual_seed(1)
+            vin = torch.randn(cols, dtype=self.dtype, device=self.device, generator=g)
             out = torch.empty(rows, dtype=self.dtype, device=self.device)
             t_csr = self._time_spmv(transpose, vin, out)
             self.attach_tiles(transpose, t)
@@ -143,11 +160,13 @@ class PdlpEngine:
         if t is None:
             N.check(self.lib.pdlp_attach_tiles(self.h, int(transpose), None), "pdlp_attach_tiles")
             self.tiles[int(transpose)] = None
+            self.kernels[int(transpose)] = "csr"
             return
         desc = N.PdlpTiles(t.lw, t.rpt, t.cap, t.nblk, t.npanel, t.groups, t.idx.data_ptr(), t.val.data_ptr(), t.tile_ptr.data_ptr(),
                            t.cnt.data_ptr())
         N.check(self.lib.pdlp_attach_tiles(self.h, int(transpose), C.byref(desc)), "pdlp_attach_tiles")
         self.tiles[int(transpose)] = t       # keep the arrays alive
+        self.kernels[int(transpose)] = "tiled" if t.groups == 1 else f"tiled/{t.groups} groups"
 
     def split_info(self, transpose: int) -> dict:
         """how a sharded product is split so that its local panels overlap the all-gather (zeros: not split)"""
@@ -306,10 +325,11 @@ class PdlpEngine:
         """``steps`` fixed-step PDHG iterations on every column of X (n x j) / Y (m x j), in place -- PDHG_step
         (spectral_casting.py:254-293); j in MV_WIDTHS, one pass over each matrix per step for all j points."""
         j = self._mv_check(X, Y)
-        work = torch.empty((2 * self.n + self.m) * j, dtype=self.dtype, device=self.device)
+        work = self._mv_work.get(j)         # kept per width: stream-ordered reuse, no allocation or sync per call
+        if work is None:
+            work = self._mv_work[j] = torch.empty((2 * self.n + self.m) * j, dtype=self.dtype, device=self.device)
         N.check(self.lib.pdlp_mv_steps(self.h, j, int(steps), float(eta), float(omega), float(theta), X.data_ptr(), Y.data_ptr(),
                                        work.data_ptr()), "pdlp_mv_steps")
-        self.stream.synchronize()           # (work is released on return)
 
     def mv_gap(self, X: torch.Tensor, Y: torch.Tensor) -> list:
         """signed duality gap (adjusted dual - primal objective) of every column -- get_best_pts (spectral_casting.py:215-234)"""

@@ -36,7 +36,7 @@ def ruiz_precondition(c, K, q, l, u, device=None, max_iter=20, eps=1e-6):
     code = _DT[dt]
     stream = torch.cuda.current_stream(dev).cuda_stream
     Ks = Kp.clone()
-    m, n = Ks.m, Ks.n
+    m, n, nnz = Ks.m, Ks.n, int(Ks.val.numel())
     vec = lambda v, ln: as_vec(v, ln, dev, dt).clone()
     c_s, q_s, l_s, u_s = vec(c, n), vec(q, m), vec(l, n), vec(u, n)
     D_row = torch.ones(m, dtype=dt, device=dev)
@@ -49,11 +49,11 @@ def ruiz_precondition(c, K, q, l, u, device=None, max_iter=20, eps=1e-6):
         N.check(lib.pdlp_csr_row_scale_factors(code, m, p(Ks.rowptr), p(Ks.val), float(eps), p(rn), stream), "row factors")   # :49-50
         N.check(lib.pdlp_vec_muldiv(code, m, p(D_row), p(rn), 1, stream), "D_row /= r")                                       # :51
         N.check(lib.pdlp_csr_div_rows(code, m, p(Ks.rowptr), p(Ks.val), p(rn), stream), "K rows /= r")                         # :52
-        N.check(lib.pdlp_csr_div_cols(code, n, p(Ks.t_rowptr), p(Ks.t_colidx), p(Ks.t_val), p(rn), stream), "K' cols /= r")
+        N.check(lib.pdlp_csr_div_cols(code, nnz, p(Ks.t_colidx), p(Ks.t_val), p(rn), stream), "K' cols /= r")
         N.check(lib.pdlp_csr_row_scale_factors(code, n, p(Ks.t_rowptr), p(Ks.t_val), float(eps), p(cn), stream), "col factors")  # :54-55
         N.check(lib.pdlp_vec_muldiv(code, n, p(D_col), p(cn), 1, stream), "D_col /= c")                                        # :56
         N.check(lib.pdlp_csr_div_rows(code, n, p(Ks.t_rowptr), p(Ks.t_val), p(cn), stream), "K' rows /= c")                    # :57
-        N.check(lib.pdlp_csr_div_cols(code, m, p(Ks.rowptr), p(Ks.colidx), p(Ks.val), p(cn), stream), "K cols /= c")
+        N.check(lib.pdlp_csr_div_cols(code, nnz, p(Ks.colidx), p(Ks.val), p(cn), stream), "K cols /= c")
         dev_from_one = C.c_double(0)
         N.check(lib.pdlp_vec_max_dev_from_one(code, m, p(rn), p(work), C.byref(dev_from_one), stream), "max|1-r|")             # :60-61
         if dev_from_one.value < eps:

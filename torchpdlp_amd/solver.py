@@ -85,6 +85,8 @@ class PdhgDriver:
         self.omega = self.t(1)
         self.res = None
         self.solved = False
+        self.checks = 0                # restart checks performed (pdhg.py:115)
+        self.check_seconds = None      # set to 0.0 to accumulate the wall time of the restart checks (synchronises around them)
 
     def start(self, sigma, x_init=None, y_init=None, theta=1.0):
         t, eng = self.t, self.eng
@@ -136,6 +138,11 @@ class PdhgDriver:
             self.tt += iters
             if self.tt % self.period != 0:                                  # pdhg.py:115
                 return iters
+        timed = self.check_seconds is not None
+        if timed:
+            eng.synchronize()
+            t_check = time.perf_counter()
+        self.checks += 1
         if self.adaptive:
             eng.flush_average()
         eng.compute_average()                                               # pdhg.py:118-119
@@ -168,6 +175,9 @@ class PdhgDriver:
                 self.trace["restarts"].append((crit, self.tt, int(use_avg)))
             eng.restart(N.AVG if use_avg else N.CUR)
             self.after_restart(r_avg if use_avg else r_cur)
+        if timed:
+            eng.synchronize()
+            self.check_seconds += time.perf_counter() - t_check
         return iters
 
     def after_restart(self, chosen=None):

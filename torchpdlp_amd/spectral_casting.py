@@ -26,13 +26,15 @@ def sample_points(eng: PdlpEngine, i: int, generator: Optional[torch.Generator] 
                   b0: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, float]:
     """2^i points on the sphere of radius r = ||K||_2 (25 power iterations) centred at (r/sqrt(n)) 1 -- :32-63"""
     n = eng.n
+    # a CPU generator replays the reference's (CPU) random stream draw for draw; without one the points are drawn on the device
+    where = "cpu" if generator is not None else eng.device
     if r is None:
         if b0 is None:
-            b0 = torch.randn(n, generator=generator, dtype=torch.float32)
+            b0 = torch.randn(n, generator=generator, dtype=torch.float32, device=where)
         r = eng.power_iteration(b0, 25)
-    pts = torch.randn(n, 2 ** i, generator=generator, dtype=torch.float32)
+    pts = torch.randn(n, 2 ** i, generator=generator, dtype=torch.float32, device=where)
     pts = pts * r / torch.norm(pts, dim=0, keepdim=True)
-    pts += (r / n ** 0.5) * torch.ones(n, 1)
+    pts += (r / n ** 0.5) * torch.ones(n, 1, device=where)
     return pts, r
 
 
@@ -41,8 +43,10 @@ def _gap(res: dict) -> float:
 
 
 def fishnet(eng: PdlpEngine, pts: torch.Tensor, s: int = 2, k: int = 32, eta: Optional[float] = None,
-            generator: Optional[torch.Generator] = None, b0: Optional[torch.Tensor] = None, multi_vector: bool = True):
-    """``fishnet`` (:65-159) on an engine; ``pts`` is n x j (moved to the device).  Returns (x, y) flattened on the device."""
+            generator: Optional[torch.Generator] = None, b0: Optional[torch.Tensor] = None, multi_vector: bool = True,
+            trace: Optional[list] = None):
+    """``fishnet`` (:65-159) on an engine; ``pts`` is n x j (moved to the device).  Returns (x, y) flattened on the device.
+    ``trace`` (a list) receives every round's (duality gaps, survivor order) of ``get_best_pts`` (:191-252)."""
     dev, dt = eng.device, eng.dtype
     pts = pts.to(device=dev, dtype=dt)                                # the population lives on the device (n x j, m x j)
     j = pts.shape[1]
@@ -50,7 +54,7 @@ def fishnet(eng: PdlpEngine, pts: torch.Tensor, s: int = 2, k: int = 32, eta: Op
     ys = torch.stack([eng.spmv(pts[:, p].contiguous(), False) for p in range(j)], dim=1)
     if eta is None:                                                   # init_PDHG_vars :161-189
         if b0 is None:
-            b0 = torch.randn(eng.n, generator=generator, dtype=torch.float32)
+            b0 = torch.randn(eng.n, generator=generator, dtype=torch.float32, device="cpu" if generator is not None else dev)
         eta = 0.9 / eng.power_iteration(b0, 50)
     q_norm, c_norm = float(torch.linalg.norm(eng.q)), float(torch.linalg.norm(eng.c))
     omega = c_norm / q_norm if (q_norm > 1e-6 and c_norm > 1e-6) else 1.0
@@ -70,6 +74,8 @@ def fishnet(eng: PdlpEngine, pts: torch.Tensor, s: int = 2, k: int = 32, eta: Op
                 gaps.append(_gap(eng.kkt(N.CUR, omega)))
         old_j = j
         order = torch.argsort(torch.tensor(gaps, dtype=torch.float32)).to(dev)           # ascending (:238)
+        if trace is not None:
+            trace.append((list(gaps), order.cpu().tolist()))
         keep = max(1, old_j // s)
         pts, ys = pts[:, order][:, :keep].clone(), ys[:, order][:, :keep].clone()
         new_j = keep
@@ -77,7 +83,7 @@ def fishnet(eng: PdlpEngine, pts: torch.Tensor, s: int = 2, k: int = 32, eta: Op
             mid, mid_y = pts.mean(dim=1, keepdim=True), ys.mean(dim=1, keepdim=True)
             new_x, new_y = [], []
             for _ in range(old_j - new_j - 1):
-                w = torch.rand(new_j, generator=generator)
+                w = torch.rand(new_j, generator=generator, device="cpu" if generator is not None else dev)
                 w = (w / w.sum()).to(device=dev, dtype=dt)
                 new_x.append(pts @ w.view(-1, 1))
                 new_y.append(ys @ w.view(-1, 1))

@@ -77,6 +77,15 @@ class Tiles:
         return sum(int(t.numel()) * t.element_size() for t in (self.idx, self.val, self.tile_ptr, self.cnt))
 
 
+def rowsum_groups(rows: int) -> int:
+    """panel groups the library's row-sum scratch has room for on a handle whose longer local side has ``rows`` rows
+    (``rowsum_groups`` in csrc/pdlp_hip.hip; ``pdlp_tile_limits`` reports the same number for a live handle): splitting a
+    row block's panels over several workgroups only pays while one workgroup per row block cannot fill 2 x 256 CUs"""
+    if rows <= NT * RPT_MAX * 128:
+        return 16
+    return 8 if rows <= NT * RPT_MAX * 512 else 1
+
+
 def _wrap_i32(v: torch.Tensor) -> torch.Tensor:
     """int64 values in [0, 2^32) -> the int32 with the same bit pattern"""
     return torch.where(v >= 2 ** 31, v - 2 ** 32, v).to(torch.int32)
@@ -139,7 +148,7 @@ def choose_rpt(nrows: int, nnz: int, ncols: int, lw: int, cap: int = CAP, ncu: i
 
 def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, nrows: int, ncols: int,
                 lw: Optional[int] = None, rpt: Optional[int] = None, cap: Optional[int] = None, max_chunk_nnz: int = 1 << 26,
-                groups: Optional[int] = None) -> Optional[Tiles]:
+                groups: Optional[int] = None, max_groups: int = 8) -> Optional[Tiles]:
     """CSR (any row lengths, columns sorted or not) -> Tiles, or None when not eligible.  Runs on the
     tensors' device with torch sorts (setup cost, done once per matrix)."""
     dev = val.device
@@ -153,7 +162,7 @@ def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, n
         lw = choose_lw(nrows, nnz, ncols)
     W = 1 << lw
     if rpt is None:
-        rpt, g_auto = choose_shape(nrows, nnz, ncols, lw, cap, rpt_max=rpt_max)
+        rpt, g_auto = choose_shape(nrows, nnz, ncols, lw, cap, rpt_max=rpt_max, max_groups=max(1, min(8, int(max_groups))))
         groups = g_auto if groups is None else groups
     groups = 1 if groups is None else int(groups)
     if not 1 <= rpt <= rpt_max:
@@ -241,7 +250,7 @@ def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, n
         b_lo = b_hi
     tile_ptr[NB * P] = base
     return Tiles(lw, rpt, cap, NB, P, nrows, ncols, out_idx[:base].contiguous(), out_val[:base].contiguous(),
-                 tile_ptr.to(torch.int32), cnt, normalize_groups(groups, P), rpt_max)
+                 tile_ptr.to(torch.int32), cnt, normalize_groups(groups, P, max(1, int(max_groups))), rpt_max)
 
 
 def tile_row_counts(t: Tiles, tile: int) -> torch.Tensor:
