@@ -35,7 +35,10 @@ extern "C" {
 #define PDLP_ERR_STATE (-3)        /* call sequence violated                       */
 #define PDLP_ERR_HIP_BASE (-1000)  /* -(1000 + hipError_t) for HIP runtime errors  */
 
-enum { PDLP_F32 = 0, PDLP_F64 = 1 };
+/* working precision: PDLP_F32 / PDLP_F64 = every vector and matrix value in that type; PDLP_MIXED = float32 matrix values
+ * (K_val, KT_val, tile values) under float64 vectors, products and sums -- for tolerances below float32 resolution on
+ * matrices whose entries are float32 numbers (the reference itself is float32 end to end, util.py:240-246) */
+enum { PDLP_F32 = 0, PDLP_F64 = 1, PDLP_MIXED = 2 };
 
 /* which iterate an evaluation refers to (reference pdhg.py:118-125) */
 enum { PDLP_CUR = 0, PDLP_AVG = 1, PDLP_PREV = 2 };
@@ -49,13 +52,15 @@ enum {
     PDLP_BUF_SCALARS = 10,   /* double[PDLP_NSCAL]: eta, omega, theta, tau, sigma, w_pending, eta_sum, k  */
     PDLP_BUF_DX = 11,        /* full length n: x - x_prev of the last step (infeasibility detection)      */
     PDLP_BUF_DY = 12,        /* full length m: y - y_prev                                                 */
-    PDLP_BUF_LAM_PREV = 13   /* local length: the previous lambda of the infeasibility detector (pdhg.py:40,101) */
+    PDLP_BUF_LAM_PREV = 13,  /* local length: the previous lambda of the infeasibility detector (pdhg.py:40,101) */
+    PDLP_BUF_GDX = 14,       /* PDLP_MIXED: full length n, FLOAT32: x+ - x of the last primal half-step (delta mode gathers from it) */
+    PDLP_BUF_GDY = 15        /* PDLP_MIXED: full length m, FLOAT32: y+ - y of the last dual half-step                              */
 };
 #define PDLP_NRED 8
 #define PDLP_NSCAL 16
 
 typedef struct pdlp_problem {
-    int32_t dtype;              /* PDLP_F32 | PDLP_F64: precision of every vector and matrix value          */
+    int32_t dtype;              /* PDLP_F32 | PDLP_F64 | PDLP_MIXED (float32 K_val / KT_val, float64 vectors)           */
     int32_t device;             /* HIP device ordinal                                                       */
     int64_t m, n;               /* global constraint / variable counts                                      */
     int64_t m_ineq;             /* the first m_ineq constraints are ">=" rows (util.py:250-261)             */
@@ -85,7 +90,8 @@ typedef struct pdlp_problem {
  * that one wave's j-th gathers are 64 consecutive sorted items.  cnt holds, per (tile, thread), five (float32) or
  * three (float64) 32-bit words of 4-bit item counts (<= 15) of the thread's rows (nibble i = row i of the thread);
  * any 64 consecutive rows (one i of one wave) may hold at most 255 items of a tile -- the kernel scans the lanes'
- * counts in 8-bit fields.  float32: rpt <= 40, cap <= 16384; float64: rpt <= 24, cap <= 8192. */
+ * counts in 8-bit fields.  float32 (and PDLP_MIXED, whose tiles are float32): rpt <= 40, cap <= 16384; float64: rpt <= 24,
+ * cap <= 8192. */
 typedef struct pdlp_tiles {
     int32_t lw, rpt, cap;       /* panel = 2^lw columns; rows per thread              ; most items per tile  */
     int32_t nblk, npanel;       /* row blocks, column panels                                               */
@@ -167,6 +173,21 @@ int pdlp_iterate(pdlp_handle h, int iters, int adaptive);
 /* fixed step, multi-rank driver: eta_total += eta and k += 1, `iters` times (pdhg.py:76,109);
  * pdlp_iterate does this itself */
 int pdlp_fixed_advance(pdlp_handle h, int iters);
+
+/* ---- delta mode (PDLP_MIXED handles; no counterpart in the float32 reference) --------------------------------------
+ * on != 0: from now on every product of an iteration and of a KKT pass runs on the FLOAT32 kernels over a float32 difference
+ * vector (PDLP_BUF_GDX = x+ - x, PDLP_BUF_GDY = y+ - y, or candidate - current in a KKT pass) and is added to a float64
+ * "anchor" product the handle carries along (K x and K'y of the current iterate):
+ *     K xbar = K x + (1 + theta) K dx,   K'y+ = K'y + K'dy        (step.py:25-38 / :74-96 in exact arithmetic)
+ * so the rounding of a product scales with the step, eps32 ||K|| ||dx||, instead of with the iterate, and the iteration
+ * streams 8 instead of 12 bytes per non-zero.  pdlp_refresh_products recomputes the anchors exactly (float64 gathers,
+ * products and sums); the handle does it by itself after pdlp_set_iterate; call it after every restart to bound the drift.
+ * Sharded problems: all-gather PDLP_BUF_GDX before pdlp_dual_half and PDLP_BUF_GDY before pdlp_primal_half (instead of xbar
+ * and y), and x, y of the current iterate before pdlp_refresh_products. */
+int pdlp_set_delta(pdlp_handle h, int on);
+int pdlp_refresh_products(pdlp_handle h);
+/* out = {delta mode on, anchors valid, the pending dy is folded into K'y} */
+int pdlp_delta_state(pdlp_handle h, int32_t out[3]);
 
 /* ---- restart machinery ---------------------------------------------------------------------- */
 /* adds the not-yet-accumulated weight of the current iterate to the sums (adaptive mode defers

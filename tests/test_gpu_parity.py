@@ -1076,7 +1076,7 @@ def test_config1_full_1Mx1M_5nnz_vs_oracle(monkeypatch, tiled):
     K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
     assert K.nnz == 5_000_000
     eng = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
-    assert eng.kernels == (["csr", "csr"] if tiled == "0" else ["tiled", "tiled"])
+    assert all(k == "csr" for k in eng.kernels) if tiled == "0" else all(k.startswith("tiled") for k in eng.kernels)
     h = lambda t: t.cpu().numpy()
     o = orc.OracleLP(lp.m, lp.n, lp.m_ineq, h(K.rowptr), h(K.colidx), h(K.val), h(lp.c), h(lp.q), h(lp.l), h(lp.u),
                      trans=(h(K.t_rowptr), h(K.t_colidx), h(K.t_val)))
@@ -1302,3 +1302,144 @@ def test_config3_one_eighth_shard_of_10Mx10M(monkeypatch):
             for a_, b_ in zip(got[adaptive][:3], ref[adaptive][:3]):
                 close(a_, b_, 2e-5)
         np.testing.assert_allclose(got[1][3], ref[1][3], rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------
+# mixed precision (float32 matrix, float64 vectors) and its delta mode -- the path for tolerances below float32 resolution
+# ---------------------------------------------------------------------------------------------------
+def _mixed_engine(g, name, delta, tiled_lw=None):
+    a = g.group(name)
+    t = lambda v, dt: torch.tensor(np.asarray(v), dtype=dt, device=DEV)
+    K = tp.CsrPair(int(a["m"]), int(a["n"]), t(a["rowptr"], torch.int32), t(a["colidx"], torch.int32), t(a["val"], torch.float32))
+    o = orc.OracleLP(a["m"], a["n"], a["m_ineq"], a["rowptr"], a["colidx"], a["val"], a["c"], a["q"], a["l"], a["u"], dtype=np.float64)
+    f64 = torch.float64
+    eng = tp.PdlpEngine.from_full(K, t(a["c"], f64), t(a["q"], f64), t(a["l"], f64), t(a["u"], f64), int(a["m_ineq"]), vec_dtype=f64,
+                                  delta=delta)
+    assert eng.mixed and eng.dtype == f64 and eng.mat_dtype == torch.float32 and eng.delta == delta
+    if tiled_lw is not None:
+        from torchpdlp_amd.tiled import build_tiles
+        for tr, (rp, ci, va), rows, cols in ((0, eng.K, eng.ml, eng.n), (1, eng.KT, eng.nl, eng.m)):
+            tl = build_tiles(rp, ci, va, rows, cols, lw=tiled_lw)
+            assert tl is not None and tl.val.dtype == torch.float32 and tl.cw == 5
+            eng.attach_tiles(tr, tl)
+    return a, K, o, eng
+
+
+@pytest.mark.parametrize("name", ["mixed_400x300", "box_200x150"])
+@pytest.mark.parametrize("tiled_lw", [None, 7])
+def test_mixed_precision_matches_the_float64_oracle(golden, name, tiled_lw):
+    """PDLP_MIXED without delta mode: the matrix is held in float32, everything else is float64 -- on a matrix whose entries are
+    float32 numbers that is the float64 algorithm bit for bit up to summation order: 1e-12 against the float64 oracle"""
+    g = golden("step_fixed.npz")
+    a, K, o, eng = _mixed_engine(g, name, False, tiled_lw)
+    x0, y0 = a["x0"].astype(np.float64), a["y0"].astype(np.float64)
+    d64 = lambda v: torch.tensor(np.asarray(v), dtype=torch.float64, device=DEV)
+    close(eng.spmv(d64(x0), False), o.spmv(x0), 1e-13)
+    close(eng.spmv(d64(y0), True), o.spmv(y0, True), 1e-13)
+    for adaptive in (False, True):
+        eng.set_iterate(d64(x0), d64(y0))
+        eng.set_step(float(a["eta"]), float(a["omega"]), 1.0, 0)
+        eng.iterate(20, adaptive)
+        xo, yo, eta = x0, y0, np.float64(a["eta"])
+        for k in range(1, 21):
+            if adaptive:
+                xo, yo, w, eta, _ = o.step_adaptive(xo, yo, eta, np.float64(a["omega"]), 1.0, k)
+            else:
+                xo, yo = o.step_fixed(xo, yo, eta, np.float64(a["omega"]), 1.0)
+        x, y = eng.get_iterate(N.CUR)
+        close(x, xo, 1e-11)
+        close(y, yo, 1e-11)
+        out, ref = eng.kkt(N.CUR, 0.7), o.kkt(xo, yo, 0.7)
+        for key in ("pr", "dr", "gap", "p", "d_adj", "kkt"):
+            np.testing.assert_allclose(out[key], float(ref[key]), rtol=1e-10, atol=1e-10)
+    s = eng.power_iteration(d64(x0), 30)
+    np.testing.assert_allclose(s, float(o.power_iter(x0, 30)), rtol=1e-11)
+
+
+@pytest.mark.parametrize("tiled_lw", [None, 7])
+def test_delta_mode_rounding_scales_with_the_step(golden, tiled_lw):
+    """delta mode: the products run on the float32 kernels over float32 differences added to float64 anchors.  Its error against
+    the float64 oracle is eps32 ||K|| ||step||, so (1) far from the optimum it is float32-like per step, (2) next to the optimum,
+    where float32 iterates cannot move any more, it tracks the float64 oracle many digits below float32 resolution, (3) the KKT
+    passes of the current / averaged / previous iterate and a restart to the average agree with the float64 oracle's"""
+    g = golden("solve_trace.npz")
+    a, K, o, eng = _mixed_engine(g, "mixed_400x300", True, tiled_lw)
+    d64 = lambda v: torch.tensor(np.asarray(v), dtype=torch.float64, device=DEV)
+    eta, omega = 0.9 / float(g.group("mixed_400x300/fixed_nopw")["sigma"]), 1.3
+    # a primal-dual point close to the optimum: a solve to 1e-10 on the non-delta mixed engine (float64 arithmetic)
+    from torchpdlp_amd.solver import run_pdlp
+    _, _, _, e0 = _mixed_engine(g, "mixed_400x300", False)
+    _, _, _, _, _, st, _ = run_pdlp(e0, tol=1e-10, verbose=False, primal_update=True, sigma=0.9 / eta, max_kkt=600_000)
+    assert st == "Solved"
+    xs, ys = (v.cpu().numpy() for v in e0.get_iterate(N.CUR))
+    rng = np.random.default_rng(0)
+    for scale, tol in ((1.0, 3e-6), (1e-6, 3e-12)):
+        x0 = np.clip(xs + scale * rng.standard_normal(o.n), o.l, o.u)
+        y0 = ys + scale * rng.standard_normal(o.m)
+        y0[:o.m_ineq] = np.maximum(y0[:o.m_ineq], 0)
+        for adaptive in (False, True):
+            eng.set_iterate(d64(x0), d64(y0))
+            eng.set_step(eta, omega, 1.0, 0)
+            assert eng.delta_state() == dict(delta=True, anchors_valid=False, dy_folded=False)
+            eng.iterate(12, adaptive)
+            assert eng.delta_state() == dict(delta=True, anchors_valid=True, dy_folded=False)
+            xo, yo, e = x0, y0, np.float64(eta)
+            for k in range(1, 13):
+                if adaptive:
+                    xo, yo, w, e, _ = o.step_adaptive(xo, yo, e, np.float64(omega), 1.0, k)
+                else:
+                    xo, yo = o.step_fixed(xo, yo, e, np.float64(omega), 1.0)
+            x, y = eng.get_iterate(N.CUR)
+            step = max(np.abs(xo - x0).max(), np.abs(yo - y0).max(), 1e-30)
+            assert np.abs(x.cpu().numpy() - xo).max() <= tol * max(1.0, step / scale), (scale, adaptive)
+            assert np.abs(y.cpu().numpy() - yo).max() <= tol * max(1.0, step / scale), (scale, adaptive)
+            # restart machinery from the anchors
+            if adaptive:
+                eng.flush_average()
+            eng.compute_average()
+            xa, ya = eng.buffer(N.BUF_X_AVG).cpu().numpy().copy(), eng.buffer(N.BUF_Y_AVG).cpu().numpy().copy()
+            xp, yp = eng.buffer(N.BUF_X_PREV).cpu().numpy().copy(), eng.buffer(N.BUF_Y_PREV).cpu().numpy().copy()
+            for which, (px, py) in ((N.CUR, (x.cpu().numpy(), y.cpu().numpy())), (N.AVG, (xa, ya)), (N.PREV, (xp, yp))):
+                out, ref = eng.kkt(which, omega), o.kkt(px, py, np.float64(omega))
+                for key in ("pr", "dr", "p", "d_adj"):
+                    np.testing.assert_allclose(out[key], float(ref[key]), rtol=1e-6, atol=1e-6 * scale, err_msg=f"{which}:{key}")
+            assert eng.delta_state()["dy_folded"]
+            eng.restart(N.AVG)                      # the anchors of the average (kept by its KKT pass) become current
+            eng.refresh_products()                  # ... and the exact ones differ from them by rounding only
+            out, ref = eng.kkt(N.CUR, omega), o.kkt(xa, ya, np.float64(omega))
+            for key in ("pr", "dr", "p", "d_adj", "kkt"):
+                np.testing.assert_allclose(out[key], float(ref[key]), rtol=1e-10, atol=1e-12, err_msg=key)
+            eng.iterate(3, adaptive)                # (first half-step after the refresh: a vector pass, no product)
+            assert eng.delta_state() == dict(delta=True, anchors_valid=True, dy_folded=False)
+
+
+def test_mixed_precision_solves_below_float32_resolution(golden):
+    """whole solves to 1e-9 relative KKT -- out of reach for float32 (and so for the reference) -- in mixed precision with and
+    without delta mode, checked by the float64 oracle's own KKT pass at the returned point and against the float64 engine"""
+    g = golden("solve_trace.npz")
+    a = g.group("mixed_400x300")
+    t = lambda v, dt: torch.tensor(np.asarray(v), dtype=dt, device=DEV)
+    f64 = torch.float64
+    K32 = tp.CsrPair(int(a["m"]), int(a["n"]), t(a["rowptr"], torch.int32), t(a["colidx"], torch.int32), t(a["val"], torch.float32))
+    K64 = tp.CsrPair(int(a["m"]), int(a["n"]), t(a["rowptr"], torch.int32), t(a["colidx"], torch.int32), t(a["val"], f64))
+    o = orc.OracleLP(a["m"], a["n"], a["m_ineq"], a["rowptr"], a["colidx"], a["val"], a["c"], a["q"], a["l"], a["u"], dtype=np.float64)
+    vecs = [t(a[k], f64) for k in ("c", "q", "l", "u")]
+    opt = float(g.group("mixed_400x300/fixed_nopw")["opt_obj"])
+    res = {}
+    for tag, K, kw in (("f64", K64, {}), ("mixed", K32, dict(precision="mixed")), ("f64-of-f32", K64, dict(precision="mixed"))):
+        for adaptive in (False, True):
+            x, obj, k, n, j, status, _ = tp.pdlp_algorithm(K, int(a["m_ineq"]), *vecs, DEV, tol=1e-9, verbose=False, adaptive=adaptive,
+                                                           primal_update=True, seed=3, max_kkt=600_000, **kw)
+            assert status == "Solved", (tag, adaptive, status, k)
+            assert x.dtype == f64
+            r = o.kkt(x.cpu().numpy().reshape(-1), np.zeros(o.m), 1.0)         # primal side by the oracle, exactly
+            assert float(r["pr"]) <= 1.5e-9 * (1 + np.linalg.norm(o.q))
+            assert abs(obj - opt) <= 1e-6 * (1 + abs(opt))
+            res[(tag, adaptive)] = (obj, k)
+    for adaptive in (False, True):
+        assert abs(res[("mixed", adaptive)][0] - res[("f64", adaptive)][0]) <= 1e-8 * (1 + abs(opt))
+    # fixed step: the delta-mode run follows the float64 run restart for restart (same number of iterations)
+    assert res[("mixed", False)][1] == res[("f64", False)][1]
+    with pytest.raises(ValueError):
+        tp.pdlp_algorithm(tp.CsrPair(K64.m, K64.n, K64.rowptr, K64.colidx, K64.val * (1 + 1e-9)), int(a["m_ineq"]), *vecs, DEV,
+                          precision="mixed", verbose=False)

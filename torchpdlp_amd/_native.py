@@ -11,11 +11,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PDLP_LIB", os.path.join(_HERE, "libpdlp_hip.so"))   # PDLP_LIB: profiling/ablation builds
 
-ABI_VERSION = 4
-PDLP_F32, PDLP_F64 = 0, 1
+ABI_VERSION = 5
+PDLP_F32, PDLP_F64, PDLP_MIXED = 0, 1, 2
 CUR, AVG, PREV = 0, 1, 2
 (BUF_X_CUR, BUF_X_PREV, BUF_XBAR, BUF_X_AVG, BUF_Y_CUR, BUF_Y_PREV, BUF_Y_AVG, BUF_RED, BUF_X_SUM, BUF_Y_SUM,
- BUF_SCALARS, BUF_DX, BUF_DY, BUF_LAM_PREV) = range(14)
+ BUF_SCALARS, BUF_DX, BUF_DY, BUF_LAM_PREV, BUF_GDX, BUF_GDY) = range(16)
 NRED, NSCAL = 8, 16
 # indices into the scalar block
 S_ETA, S_OMEGA, S_THETA, S_TAU, S_SIGMA, S_WPEND, S_ETASUM, S_K, S_INV1PT, S_ACCEPT, S_ETABAR, S_DEN = range(12)
@@ -62,6 +62,9 @@ SIGNATURES = {
     "pdlp_adaptive_reduce": (_I, [_H]),
     "pdlp_adaptive_update": (_I, [_H]),
     "pdlp_iterate": (_I, [_H, _I, _I]),
+    "pdlp_set_delta": (_I, [_H, _I]),
+    "pdlp_refresh_products": (_I, [_H]),
+    "pdlp_delta_state": (_I, [_H, C.POINTER(C.c_int32)]),
     "pdlp_fixed_advance": (_I, [_H, _I]),
     "pdlp_flush_average": (_I, [_H]),
     "pdlp_compute_average": (_I, [_H]),

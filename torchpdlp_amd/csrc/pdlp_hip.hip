@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "pdlp_hip.h"
@@ -154,7 +155,14 @@ void build_schedule_host(const std::vector<int32_t>& rp, int64_t rows, std::vect
 struct pdlp_solver {
     pdlp_problem p;
     hipStream_t stream;
-    size_t es;                    // element size
+    size_t es;                    // element size of the vectors
+    bool mixed;                   // PDLP_MIXED: float32 matrix values under float64 vectors
+    // delta mode (mixed precision only): every product of the iteration runs on the float32 kernels over a float32 DIFFERENCE
+    // vector and is added to a float64 "anchor" product that is carried along: kxb[0] = K x_cur, ktyr = K'y (of y_cur once
+    // dy_folded, else of the previous y with gdy = y_cur - y_prev still to be folded in by the next product with K')
+    bool delta, anchors_valid, dy_folded;
+    char* ktyr;                   // [nl] float64 running K'y
+    float *gdx, *gdy;             // full-length float32 difference vectors the float32 kernels gather from
     int64_t nl, ml;               // local variable / constraint counts
     int ineq_end;                 // local rows below this index are inequalities
     Schedule sK, sKT;
@@ -207,20 +215,22 @@ void free_handle(pdlp_handle h)
 
 // partial row sums of `vgroups` panel groups over `vtotal` panels in virtual order (see k_tiled_fused) into
 // rowsum[slot0 .. slot0 + vgroups); the epilogue functor is not used by these launches
-template <typename T>
+template <typename T, typename TV>
 void launch_tiled_groups(pdlp_handle h, const Schedule& s, int rows, const void* vin, hipStream_t stream, int vgroups, int vtotal,
                          int skip_lo, int skip_len, int slot0)
 {
     const int ppg = (vtotal + vgroups - 1) / vgroups;
     const int groups = (vtotal + ppg - 1) / ppg;          // no group without panels
     StoreEpi<T> none{nullptr};
-    hipLaunchKernelGGL((k_tiled_fused<T, StoreEpi<T>, false>), dim3(s.t.nblk * groups), dim3(TNT), 0, stream, s.t.idx,
-                       (const T*)s.t.val, s.t.tile_ptr, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, ppg, vtotal, skip_lo,
+    hipLaunchKernelGGL((k_tiled_fused<T, TV, StoreEpi<T>, false>), dim3(s.t.nblk * groups), dim3(TNT), 0, stream, s.t.idx,
+                       (const TV*)s.t.val, s.t.tile_ptr, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, ppg, vtotal, skip_lo,
                        skip_len, slot0, (const T*)vin, (T*)h->rowsum, h->rs_stride, none, (double*)nullptr);
 }
 
-template <typename T, class Epi>
-int launch_csr(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* partials)
+// one product with K (or K') over the vector vin with the epilogue fused: T = type of vin, of the row sums and of what the
+// epilogue receives, TV = type of the stored matrix values
+template <typename T, typename TV, class Epi>
+int launch_mat(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* partials)
 {
     if (!h->use_split && (h->sK.pending || h->sKT.pending)) {
         // an early local-panel product that nobody is going to consume (the caller changed course): let it finish
@@ -233,18 +243,18 @@ int launch_csr(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* 
     if (s.tiled) {
         const int rows = (int)(transpose ? h->nl : h->ml);
         if (s.t.groups == 1 && !(s.pending && h->use_split)) {
-            hipLaunchKernelGGL((k_tiled_fused<T, Epi, true>), dim3(s.t.nblk), dim3(TNT), 0, h->stream, s.t.idx, (const T*)s.t.val,
+            hipLaunchKernelGGL((k_tiled_fused<T, TV, Epi, true>), dim3(s.t.nblk), dim3(TNT), 0, h->stream, s.t.idx, (const TV*)s.t.val,
                                s.t.tile_ptr, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, s.t.npanel, s.t.npanel,
                                s.t.npanel, 0, 0, (const T*)vin, (T*)h->rowsum, h->rs_stride, epi, partials);
         } else if (s.pending && h->use_split) {
             // the local panels were multiplied by pdlp_*_half_begin on the side stream; now the others, then the sum
-            launch_tiled_groups<T>(h, s, rows, vin, h->stream, s.slotsB, s.t.npanel - (s.loc_pb - s.loc_pa), s.loc_pa,
+            launch_tiled_groups<T, TV>(h, s, rows, vin, h->stream, s.slotsB, s.t.npanel - (s.loc_pb - s.loc_pa), s.loc_pa,
                                    s.loc_pb - s.loc_pa, s.slotsA);
             HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_out, 0));
             hipLaunchKernelGGL((k_rowsum_epilogue<T, Epi>), dim3(grid_for(rows)), dim3(BLOCK), 0, h->stream, (const T*)h->rowsum,
                                s.slotsA + s.slotsB, h->rs_stride, rows, epi, partials);
         } else {
-            launch_tiled_groups<T>(h, s, rows, vin, h->stream, s.t.groups, s.t.npanel, s.t.npanel, 0, 0);
+            launch_tiled_groups<T, TV>(h, s, rows, vin, h->stream, s.t.groups, s.t.npanel, s.t.npanel, 0, 0);
             hipLaunchKernelGGL((k_rowsum_epilogue<T, Epi>), dim3(grid_for(rows)), dim3(BLOCK), 0, h->stream, (const T*)h->rowsum,
                                s.t.groups, h->rs_stride, rows, epi, partials);
         }
@@ -253,14 +263,24 @@ int launch_csr(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* 
     }
     const int32_t* rp = transpose ? h->p.KT_rowptr : h->p.K_rowptr;
     const int32_t* ci = transpose ? h->p.KT_colidx : h->p.K_colidx;
-    const T* va = (const T*)(transpose ? h->p.KT_val : h->p.K_val);
-    hipLaunchKernelGGL((k_csr_fused<T, Epi>), dim3(s.grid), dim3(BLOCK), 0, h->stream, s.blk, s.nblk, s.lch, s.nchunks,
+    const TV* va = (const TV*)(transpose ? h->p.KT_val : h->p.K_val);
+    hipLaunchKernelGGL((k_csr_fused<T, TV, Epi>), dim3(s.grid), dim3(BLOCK), 0, h->stream, s.blk, s.nblk, s.lch, s.nchunks,
                        (T*)s.longpart, rp, ci, va, (const T*)vin, epi, partials);
     if (s.nlong > 0)
         hipLaunchKernelGGL((k_long_rows<T, Epi>), dim3(s.lgrid), dim3(BLOCK), 0, h->stream, s.lrow, s.lptr, s.nlong,
                            (const T*)s.longpart, epi, partials + (size_t)s.grid * NACC);
     HIP_TRY(hipGetLastError());
     return PDLP_OK;
+}
+
+// the product in the handle's working precision T (the matrix is float32 under float64 vectors in mixed precision)
+template <typename T, class Epi>
+int launch_csr(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* partials)
+{
+    if constexpr (std::is_same<T, double>::value) {
+        if (h->mixed) return launch_mat<double, float, Epi>(h, transpose, vin, epi, partials);
+    }
+    return launch_mat<T, T, Epi>(h, transpose, vin, epi, partials);
 }
 
 inline int grid_of(const Schedule& s, int64_t rows)
@@ -431,10 +451,134 @@ template <typename T> int half_begin_t(pdlp_handle h, bool transpose, const void
     const int rows = (int)(transpose ? h->nl : h->ml);
     HIP_TRY(hipEventRecord(h->ev_in, h->stream));
     HIP_TRY(hipStreamWaitEvent(h->gstream, h->ev_in, 0));
-    launch_tiled_groups<T>(h, s, rows, vin, h->gstream, s.slotsA, s.loc_pb - s.loc_pa, 0, s.loc_pa, 0);
+    if (h->delta) launch_tiled_groups<float, float>(h, s, rows, transpose ? (const void*)h->gdy : (const void*)h->gdx, h->gstream, s.slotsA,
+                                                    s.loc_pb - s.loc_pa, 0, s.loc_pa, 0);
+    else if (std::is_same<T, double>::value && h->mixed)
+        launch_tiled_groups<double, float>(h, s, rows, vin, h->gstream, s.slotsA, s.loc_pb - s.loc_pa, 0, s.loc_pa, 0);
+    else launch_tiled_groups<T, T>(h, s, rows, vin, h->gstream, s.slotsA, s.loc_pb - s.loc_pa, 0, s.loc_pa, 0);
     HIP_TRY(hipEventRecord(h->ev_out, h->gstream));
     HIP_TRY(hipGetLastError());
     s.pending = true;
+    return PDLP_OK;
+}
+
+// ---- delta mode (mixed precision) ------------------------------------------------------------------
+// exact anchors: KX = K x_cur and KTY = K'y_cur by the mixed-precision kernels (float64 gathers, products and sums)
+int delta_refresh(pdlp_handle h)
+{
+    int rc;
+    StoreEpi<double> ex{(double*)h->kxb[0]};
+    if ((rc = launch_mat<double, float, StoreEpi<double>>(h, false, h->xb[h->ix_cur], ex, h->partB)) != PDLP_OK) return rc;
+    StoreEpi<double> ey{(double*)h->ktyr};
+    if ((rc = launch_mat<double, float, StoreEpi<double>>(h, true, h->yb[h->ix_cur], ey, h->partA)) != PDLP_OK) return rc;
+    h->anchors_valid = true;
+    h->dy_folded = true;
+    h->kx_valid = true;
+    return PDLP_OK;
+}
+
+// a float64 epilogue over a float64 vector of finished products (no matrix pass)
+template <class Epi> int delta_vector_pass(pdlp_handle h, int64_t rows, const double* products, Epi e, double* partials)
+{
+    if (rows == 0) return PDLP_OK;
+    hipLaunchKernelGGL((k_rowsum_epilogue<double, Epi>), dim3(grid_for(rows)), dim3(BLOCK), 0, h->stream, products, 1, (int64_t)0,
+                       (int)rows, e, partials);
+    HIP_TRY(hipGetLastError());
+    return PDLP_OK;
+}
+
+template <bool ADAPT> int delta_primal_half_a(pdlp_handle h)
+{
+    int rc;
+    if (!h->anchors_valid && (rc = delta_refresh(h)) != PDLP_OK) return rc;
+    DeltaPrimalEpi<ADAPT> e{(const double*)xloc<double>(h, h->ix_cur), xloc<double>(h, h->ix_prev), h->gdx + h->p.col0, (const double*)h->p.c,
+                            (const double*)h->p.l, (const double*)h->p.u, (double*)h->x_sum, (double*)h->ktyr, h->sc};
+    if (h->dy_folded && !h->sKT.pending) {
+        // K'y of the current y is already in the anchor (a restart check folded dy in, or the anchors are fresh): vector pass
+        h->last_gridA = h->nl > 0 ? grid_for(h->nl) : 0;
+        if (h->nl == 0) return PDLP_OK;
+        hipLaunchKernelGGL((k_rowsum_epilogue<float, DeltaPrimalEpi<ADAPT>>), dim3(grid_for(h->nl)), dim3(BLOCK), 0, h->stream,
+                           (const float*)nullptr, 0, (int64_t)0, (int)h->nl, e, h->partA);
+        HIP_TRY(hipGetLastError());
+        return PDLP_OK;
+    }
+    h->last_gridA = grid_of(h->sKT, h->nl);
+    h->use_split = true;
+    rc = launch_mat<float, float, DeltaPrimalEpi<ADAPT>>(h, true, h->gdy, e, h->partA);
+    h->use_split = false; h->sKT.pending = false;
+    h->dy_folded = true;       // (the anchor now belongs to the current y)
+    return rc;
+}
+
+template <bool ADAPT> int delta_dual_half_a(pdlp_handle h)
+{
+    DeltaDualEpi<ADAPT> e{(const double*)yloc<double>(h, h->ix_cur), yloc<double>(h, h->ix_prev), h->gdy + h->p.row0, (const double*)h->p.q,
+                          (double*)h->y_sum, (double*)h->kxb[0], h->sc, h->ineq_end};
+    h->last_gridB = grid_of(h->sK, h->ml);
+    h->use_split = true;
+    const int rc = launch_mat<float, float, DeltaDualEpi<ADAPT>>(h, false, h->gdx, e, h->partB);
+    h->use_split = false; h->sK.pending = false;
+    if (rc != PDLP_OK) return rc;
+    const int t = h->ix_cur;
+    h->ix_cur = h->ix_prev;
+    h->ix_prev = t;
+    h->cand_valid[0] = h->cand_valid[1] = false;
+    h->dy_folded = false;      // gdy = y_cur - y_prev waits for the next product with K'
+    return PDLP_OK;
+}
+
+int delta_primal_half(pdlp_handle h, int adaptive) { return adaptive ? delta_primal_half_a<true>(h) : delta_primal_half_a<false>(h); }
+int delta_dual_half(pdlp_handle h, int adaptive) { return adaptive ? delta_dual_half_a<true>(h) : delta_dual_half_a<false>(h); }
+
+// KKT sums of a candidate from the anchors: the current iterate needs at most the pending K'dy; the averaged / previous
+// iterate two float32 products over float32(candidate - current) added to the anchors
+int delta_kkt_local(pdlp_handle h, int which)
+{
+    int rc;
+    if (!h->anchors_valid && (rc = delta_refresh(h)) != PDLP_OK) return rc;
+    typedef KktDualEpi<double, false> KD;
+    typedef KktPrimalEpi<double, false> KP;
+    if (which == PDLP_CUR) {
+        KD ed{xloc<double>(h, h->ix_cur), (const double*)h->p.c, (const double*)h->p.l, (const double*)h->p.u, nullptr, nullptr};
+        if (!h->dy_folded) {
+            AnchorEpi<KD, true> e{ed, (double*)h->ktyr};
+            if ((rc = launch_mat<float, float, AnchorEpi<KD, true>>(h, true, h->gdy, e, h->partA)) != PDLP_OK) return rc;
+            h->dy_folded = true;
+            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partA, grid_of(h->sKT, h->nl), 4, h->red, 0);
+        } else {
+            if ((rc = delta_vector_pass(h, h->nl, (const double*)h->ktyr, ed, h->partA)) != PDLP_OK) return rc;
+            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partA, h->nl > 0 ? grid_for(h->nl) : 0, 4, h->red, 0);
+        }
+        KP ep{yloc<double>(h, h->ix_cur), (const double*)h->p.q, nullptr, nullptr, h->ineq_end};
+        if ((rc = delta_vector_pass(h, h->ml, (const double*)h->kxb[0], ep, h->partB)) != PDLP_OK) return rc;
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partB, h->ml > 0 ? grid_for(h->ml) : 0, 2, h->red, 4);
+        HIP_TRY(hipGetLastError());
+        h->cand_valid[0] = true;
+        return PDLP_OK;
+    }
+    if (!h->dy_folded) {
+        FoldEpi f{(double*)h->ktyr};
+        if ((rc = launch_mat<float, float, FoldEpi>(h, true, h->gdy, f, h->partA)) != PDLP_OK) return rc;
+        h->dy_folded = true;
+    }
+    const int ix = which == PDLP_AVG ? h->ix_avg : h->ix_prev;
+    // the full-length differences (every rank holds the complete candidate and the complete current iterate)
+    hipLaunchKernelGGL(k_diff_f32, dim3(grid_for(h->p.n)), dim3(BLOCK), 0, h->stream, h->p.n, h->gdx, (const double*)h->xb[ix],
+                       (const double*)h->xb[h->ix_cur]);
+    hipLaunchKernelGGL(k_diff_f32, dim3(grid_for(h->p.m)), dim3(BLOCK), 0, h->stream, h->p.m, h->gdy, (const double*)h->yb[ix],
+                       (const double*)h->yb[h->ix_cur]);
+    // K'y and K x of the averaged iterate are kept: a restart to it adopts them as the new anchors
+    KD ed{xloc<double>(h, ix), (const double*)h->p.c, (const double*)h->p.l, (const double*)h->p.u, nullptr,
+          which == PDLP_AVG ? (double*)h->ktyb[1] : nullptr};
+    AnchorEpi<KD, false> ea{ed, (double*)h->ktyr};
+    if ((rc = launch_mat<float, float, AnchorEpi<KD, false>>(h, true, h->gdy, ea, h->partA)) != PDLP_OK) return rc;
+    KP ep{yloc<double>(h, ix), (const double*)h->p.q, nullptr, which == PDLP_AVG ? (double*)h->kxb[2] : nullptr, h->ineq_end};
+    AnchorEpi<KP, false> eb{ep, (double*)h->kxb[0]};
+    if ((rc = launch_mat<float, float, AnchorEpi<KP, false>>(h, false, h->gdx, eb, h->partB)) != PDLP_OK) return rc;
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partA, grid_of(h->sKT, h->nl), 4, h->red, 0);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partB, grid_of(h->sK, h->ml), 2, h->red, 4);
+    HIP_TRY(hipGetLastError());
+    if (which == PDLP_AVG) h->cand_valid[1] = true;
     return PDLP_OK;
 }
 
@@ -622,7 +766,7 @@ template <typename T> int mv_gap_t(pdlp_handle h, int nvp, const void* X, const 
 int check_problem(const pdlp_problem* p)
 {
     if (!p) return PDLP_ERR_INVALID;
-    if (p->dtype != PDLP_F32 && p->dtype != PDLP_F64) return PDLP_ERR_INVALID;
+    if (p->dtype != PDLP_F32 && p->dtype != PDLP_F64 && p->dtype != PDLP_MIXED) return PDLP_ERR_INVALID;
     if (p->m < 0 || p->n < 0 || p->m_ineq < 0 || p->m_ineq > p->m) return PDLP_ERR_INVALID;
     if (p->row0 < 0 || p->row1 < p->row0 || p->row1 > p->m) return PDLP_ERR_INVALID;
     if (p->col0 < 0 || p->col1 < p->col0 || p->col1 > p->n) return PDLP_ERR_INVALID;
@@ -679,6 +823,10 @@ int64_t layout(const pdlp_problem* p, int64_t nnzK, int64_t nnzKT, int64_t* offs
     offs[k++] = c.take(nl * es);                                  // 32    K'dy
     offs[k++] = c.take(nl * es);                                  // 33    K'y from KKT(current)
     offs[k++] = c.take(nl * es);                                  // 34    K'y from KKT(average)
+    const bool mixed = p->dtype == PDLP_MIXED;                    // delta mode: running K'y, float32 difference vectors
+    offs[k++] = c.take(mixed ? nl * es : 0);                      // 35    ktyr
+    offs[k++] = c.take(mixed ? p->n * 4 : 0);                     // 36    gdx
+    offs[k++] = c.take(mixed ? p->m * 4 : 0);                     // 37    gdy
     return c.off;
 }
 
@@ -702,7 +850,7 @@ int read_last_rowptr(const int32_t* rp, int64_t rows, int64_t* nnz, hipStream_t 
 // ================================================================================================
 extern "C" {
 
-int pdlp_abi_version(void) { return 4; }   // 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
+int pdlp_abi_version(void) { return 5; }   // 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
 
 const char* pdlp_strerror(int code)
 {
@@ -750,6 +898,8 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     h->p = *p;
     h->stream = (hipStream_t)p->stream;
     h->es = p->dtype == PDLP_F32 ? 4 : 8;
+    h->mixed = p->dtype == PDLP_MIXED;
+    h->delta = false; h->anchors_valid = false; h->dy_folded = false;
     h->nl = nl;
     h->ml = ml;
     int64_t ie = p->m_ineq - p->row0;
@@ -767,6 +917,7 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     h->rowsum = (void*)(w + offs[20]);
     h->dxf = w + offs[29]; h->dyf = w + offs[30]; h->lam_prev = w + offs[31]; h->ktdy = w + offs[32];
     h->ktyb[0] = w + offs[33]; h->ktyb[1] = w + offs[34];
+    h->ktyr = w + offs[35]; h->gdx = (float*)(w + offs[36]); h->gdy = (float*)(w + offs[37]);
     h->kty_cur = -1;
     h->no_kty_reuse = std::getenv("PDLP_NO_KTY_REUSE") != nullptr;
     h->rs_stride = (nl > ml ? nl : ml) + (int64_t)TNT * TRPT_MAX_ANY;
@@ -854,6 +1005,8 @@ int pdlp_buffer_ptr(pdlp_handle h, int which, void** ptr)
         case PDLP_BUF_DX: *ptr = h->dxf; break;
         case PDLP_BUF_DY: *ptr = h->dyf; break;
         case PDLP_BUF_LAM_PREV: *ptr = h->lam_prev; break;
+        case PDLP_BUF_GDX: if (!h->mixed) return PDLP_ERR_STATE; *ptr = h->gdx; break;
+        case PDLP_BUF_GDY: if (!h->mixed) return PDLP_ERR_STATE; *ptr = h->gdy; break;
         default: return PDLP_ERR_INVALID;
     }
     return PDLP_OK;
@@ -866,8 +1019,8 @@ int pdlp_attach_tiles(pdlp_handle h, int transpose, const pdlp_tiles* t)
     drop_graphs(h);               // captured launches name the old kernel and arrays
     if (!t) { s.tiled = false; configure_split(h, transpose != 0); return PDLP_OK; }
     const int64_t rows = transpose ? h->nl : h->ml;
-    const int rpt_max = h->p.dtype == PDLP_F32 ? TileCfg<float>::RPT_MAX : TileCfg<double>::RPT_MAX;
-    const int cap_max = h->p.dtype == PDLP_F32 ? TileCfg<float>::CAP : TileCfg<double>::CAP;
+    const int rpt_max = h->p.dtype == PDLP_F64 ? TileCfg<double, double>::RPT_MAX : TileCfg<float, float>::RPT_MAX;   // (mixed: float32 tiles)
+    const int cap_max = h->p.dtype == PDLP_F64 ? TileCfg<double, double>::CAP : TileCfg<float, float>::CAP;
     if (t->rpt < 1 || t->rpt > rpt_max || t->cap > cap_max || t->lw < 4 || t->lw > 16) return PDLP_ERR_INVALID;
     const int64_t rb = (int64_t)TNT * t->rpt;
     if (t->nblk != (int)((rows + rb - 1) / rb) || t->npanel < 1) return PDLP_ERR_INVALID;
@@ -897,6 +1050,7 @@ int pdlp_set_iterate(pdlp_handle h, const void* x_local, const void* y_local)
     h->kx_valid = false;
     h->cand_valid[0] = h->cand_valid[1] = false;
     h->kty_cur = -1;
+    h->anchors_valid = false; h->dy_folded = false;
     return PDLP_OK;
 }
 
@@ -941,25 +1095,29 @@ int pdlp_get_scalars(pdlp_handle h, double out[PDLP_NSCAL])
 int pdlp_primal_half(pdlp_handle h, int adaptive)
 {
     if (!h) return PDLP_ERR_INVALID;
+    if (h->delta) return delta_primal_half(h, adaptive);
     return DISPATCH(h, primal_half_t, h, adaptive);
 }
 
 int pdlp_dual_half(pdlp_handle h, int adaptive)
 {
     if (!h) return PDLP_ERR_INVALID;
+    if (h->delta) return delta_dual_half(h, adaptive);
     return DISPATCH(h, dual_half_t, h, adaptive);
 }
 
 int pdlp_primal_half_begin(pdlp_handle h)
 {
     if (!h) return PDLP_ERR_INVALID;
+    if (h->delta && !h->anchors_valid) return PDLP_OK;
     return DISPATCH(h, half_begin_t, h, true, h->yb[h->ix_cur]);
 }
 
 int pdlp_dual_half_begin(pdlp_handle h, int adaptive)
 {
     if (!h) return PDLP_ERR_INVALID;
-    if (adaptive && !h->kx_valid) return PDLP_OK;        // the K x refresh ahead of this half-step uses the same scratch
+    if (h->delta && !h->anchors_valid) return PDLP_OK;
+    if (!h->delta && adaptive && !h->kx_valid) return PDLP_OK;        // the K x refresh ahead of this half-step uses the same scratch
     return DISPATCH(h, half_begin_t, h, false, h->xbar);
 }
 
@@ -976,8 +1134,8 @@ int pdlp_tile_limits(pdlp_handle h, int32_t out[4])
     if (!h || !out) return PDLP_ERR_INVALID;
     out[0] = h->rs_groups;
     out[1] = (int32_t)(h->part_blocks > INT32_MAX ? INT32_MAX : h->part_blocks);
-    out[2] = h->p.dtype == PDLP_F32 ? TileCfg<float>::RPT_MAX : TileCfg<double>::RPT_MAX;
-    out[3] = h->p.dtype == PDLP_F32 ? TileCfg<float>::CAP : TileCfg<double>::CAP;
+    out[2] = h->p.dtype == PDLP_F64 ? TileCfg<double, double>::RPT_MAX : TileCfg<float, float>::RPT_MAX;
+    out[3] = h->p.dtype == PDLP_F64 ? TileCfg<double, double>::CAP : TileCfg<float, float>::CAP;
     return PDLP_OK;
 }
 
@@ -1120,6 +1278,7 @@ int pdlp_kkt_local(pdlp_handle h, int which, int unscaled)
 {
     if (!h || which < PDLP_CUR || which > PDLP_PREV) return PDLP_ERR_INVALID;
     if (unscaled && (!h->p.d_col || !h->p.d_row)) return PDLP_ERR_STATE;
+    if (h->delta) return unscaled ? PDLP_ERR_STATE : delta_kkt_local(h, which);
     return DISPATCH(h, kkt_local_t, h, which, unscaled);
 }
 
@@ -1150,6 +1309,23 @@ int pdlp_restart(pdlp_handle h, int which)
         const int t = h->ix_cur;
         h->ix_cur = h->ix_avg;
         h->ix_avg = t;
+    }
+    if (h->delta) {                // the anchors follow the iterate: K x and K'y of the average were kept by its KKT pass
+        if (which == PDLP_AVG) {
+            if (h->cand_valid[1]) {
+                char* t = h->kxb[0]; h->kxb[0] = h->kxb[2]; h->kxb[2] = t;
+                t = h->ktyr; h->ktyr = h->ktyb[1]; h->ktyb[1] = t;
+                h->dy_folded = true;
+            } else {
+                h->anchors_valid = false;
+            }
+        }
+        h->cand_valid[0] = h->cand_valid[1] = false;
+        HIP_TRY(hipMemsetAsync(h->x_sum, 0, h->nl * h->es, h->stream));
+        HIP_TRY(hipMemsetAsync(h->y_sum, 0, h->ml * h->es, h->stream));
+        hipLaunchKernelGGL(k_reset_average, dim3(1), dim3(1), 0, h->stream, h->sc);
+        HIP_TRY(hipGetLastError());
+        return PDLP_OK;
     }
     if (h->cand_valid[cand]) {     // K x and K'y of the chosen point were produced by its KKT pass
         char* t = h->kxb[0];
@@ -1215,14 +1391,14 @@ int pdlp_infeas_finish(pdlp_handle h, double tol, int32_t* status, double diag[8
 int pdlp_mv_steps(pdlp_handle h, int nvp, int steps, double eta, double omega, double theta, void* X, void* Y, void* work)
 {
     if (!h || !X || !Y || !work || steps < 0 || (nvp != 8 && nvp != 16 && nvp != 32)) return PDLP_ERR_INVALID;
-    if (h->nl != h->p.n || h->ml != h->p.m) return PDLP_ERR_STATE;
+    if (h->nl != h->p.n || h->ml != h->p.m || h->mixed) return PDLP_ERR_STATE;
     return DISPATCH(h, mv_steps_t, h, nvp, steps, eta, omega, theta, X, Y, work);
 }
 
 int pdlp_mv_gap(pdlp_handle h, int nvp, const void* X, const void* Y, void* work, double* gaps)
 {
     if (!h || !X || !Y || !work || !gaps || (nvp != 8 && nvp != 16 && nvp != 32)) return PDLP_ERR_INVALID;
-    if (h->nl != h->p.n || h->ml != h->p.m) return PDLP_ERR_STATE;
+    if (h->nl != h->p.n || h->ml != h->p.m || h->mixed) return PDLP_ERR_STATE;
     return DISPATCH(h, mv_gap_t, h, nvp, X, Y, work, gaps);
 }
 
@@ -1237,6 +1413,34 @@ int pdlp_power_iteration(pdlp_handle h, const void* b0, int iters, void* work_n,
     if (!h || !b0 || !work_n || !work_m || !sigma || iters < 0) return PDLP_ERR_INVALID;
     if (h->nl != h->p.n || h->ml != h->p.m) return PDLP_ERR_STATE;
     return DISPATCH(h, power_iteration_t, h, b0, iters, work_n, work_m, sigma);
+}
+
+int pdlp_set_delta(pdlp_handle h, int on)
+{
+    if (!h) return PDLP_ERR_INVALID;
+    if (on && !h->mixed) return PDLP_ERR_STATE;           // float32 matrix values under float64 vectors only
+    if ((on != 0) == h->delta) return PDLP_OK;
+    drop_graphs(h);
+    h->graph_ok = false;
+    h->delta = on != 0;
+    h->anchors_valid = false; h->dy_folded = false;
+    h->kx_valid = false; h->cand_valid[0] = h->cand_valid[1] = false; h->kty_cur = -1;
+    return PDLP_OK;
+}
+
+int pdlp_refresh_products(pdlp_handle h)
+{
+    if (!h) return PDLP_ERR_INVALID;
+    if (h->delta) return delta_refresh(h);
+    if (h->p.dtype == PDLP_F32) return refresh_kx_t<float>(h);
+    return refresh_kx_t<double>(h);
+}
+
+int pdlp_delta_state(pdlp_handle h, int32_t out[3])
+{
+    if (!h || !out) return PDLP_ERR_INVALID;
+    out[0] = h->delta; out[1] = h->anchors_valid; out[2] = h->dy_folded;
+    return PDLP_OK;
 }
 
 // ---- Ruiz building blocks -------------------------------------------------------------------------

@@ -50,14 +50,14 @@ def _pad_vec(v: torch.Tensor, have: int, a: int, b: int, fill: float = 0.0) -> t
     return out
 
 
-def shard_arrays(K: CsrPair, c, q, l, u, m_ineq: int, rank: int, world: int, d_col=None, d_row=None) -> dict:
+def shard_arrays(K: CsrPair, c, q, l, u, m_ineq: int, rank: int, world: int, d_col=None, d_row=None, vec_dtype=None) -> dict:
     """This rank's blocks of a problem held in full: keyword arguments for ``PdlpEngine`` (minus ``comm``)."""
     W, r = world, rank
     m, n = K.m, K.n
     mp, np_ = padded(m, W), padded(n, W)
     r0, r1 = block(mp, r, W)
     c0, c1 = block(np_, r, W)
-    dev, dt = K.device, K.dtype
+    dev, dt = K.device, (K.dtype if vec_dtype is None else vec_dtype)
     vec = lambda v, ln: as_vec(v, ln, dev, dt)
     a, b = int(K.rowptr[min(r0, m)]), int(K.rowptr[min(r1, m)])
     K_rows = (_pad_rowptr(K.rowptr, m, r0, r1), K.colidx[a:b].contiguous(), K.val[a:b].contiguous())
@@ -70,12 +70,12 @@ def shard_arrays(K: CsrPair, c, q, l, u, m_ineq: int, rank: int, world: int, d_c
                 rows=(r0, r1), cols=(c0, c1), d_col=opt(d_col, n, c0, c1, 1.0), d_row=opt(d_row, m, r0, r1, 1.0))
 
 
-def shard_engine(K: CsrPair, c, q, l, u, m_ineq: int, comm: Optional[Comm], d_col=None, d_row=None) -> PdlpEngine:
+def shard_engine(K: CsrPair, c, q, l, u, m_ineq: int, comm: Optional[Comm], d_col=None, d_row=None, vec_dtype=None) -> PdlpEngine:
     """Engine for this rank's block of a problem every rank holds in full (small/medium problems, tests,
     and the benchmark, where every rank generates the same seeded instance and keeps only its block)."""
     if comm is None or comm.world == 1:
-        return PdlpEngine.from_full(K, c, q, l, u, m_ineq, d_col=d_col, d_row=d_row)
-    return PdlpEngine(comm=comm, **shard_arrays(K, c, q, l, u, m_ineq, comm.rank, comm.world, d_col, d_row))
+        return PdlpEngine.from_full(K, c, q, l, u, m_ineq, d_col=d_col, d_row=d_row, vec_dtype=vec_dtype)
+    return PdlpEngine(comm=comm, vec_dtype=vec_dtype, **shard_arrays(K, c, q, l, u, m_ineq, comm.rank, comm.world, d_col, d_row, vec_dtype))
 
 
 def gather_solution(eng: PdlpEngine, x_local: torch.Tensor, n_true: int) -> torch.Tensor:

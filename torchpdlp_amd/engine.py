@@ -19,6 +19,11 @@ from . import tiled as _tiled
 _DT = {torch.float32: N.PDLP_F32, torch.float64: N.PDLP_F64}
 
 
+def values_are_float32(val: torch.Tensor) -> bool:
+    """every entry of a float64 array is a float32 number (so the matrix can be held in float32 without changing the LP)"""
+    return val.dtype == torch.float32 or bool((val.float().to(val.dtype) == val).all())
+
+
 class Comm:
     """One process per GPU.  Vectors are sharded in equal blocks (the LP is padded so the sizes divide)."""
 
@@ -58,7 +63,12 @@ class PdlpEngine:
     """
 
     def __init__(self, m: int, n: int, m_ineq: int, K_rows, KT_rows, c, q, l, u, rows: Tuple[int, int] = None,
-                 cols: Tuple[int, int] = None, d_col=None, d_row=None, comm: Optional[Comm] = None):
+                 cols: Tuple[int, int] = None, d_col=None, d_row=None, comm: Optional[Comm] = None, vec_dtype=None,
+                 delta: Optional[bool] = None):
+        """``vec_dtype=torch.float64`` over float32 matrix values selects the mixed precision (``PDLP_MIXED``): float64 vectors,
+        products and sums on a float32 matrix (12 -> 8 bytes per non-zero); ``delta`` (default: ``PDLP_DELTA`` in the environment,
+        else on) then runs the iterations on the float32 kernels over float32 difference vectors added to float64 anchor
+        products (``pdlp_set_delta`` in include/pdlp_hip.h)."""
         self.lib = N.load()
         rows = (0, m) if rows is None else rows
         cols = (0, n) if cols is None else cols
@@ -69,22 +79,29 @@ class PdlpEngine:
         if self.comm is None and (self.ml != self.m or self.nl != self.n):
             raise ValueError("a sharded problem needs a communicator")
         val = K_rows[2]
-        self.device, self.dtype = val.device, val.dtype
+        self.device, self.mat_dtype = val.device, val.dtype
+        self.dtype = self.mat_dtype if vec_dtype is None else vec_dtype       # the working precision: vectors, sums, scalars
         if self.device.type != "cuda":
             raise N.PdlpError("PdlpEngine needs the problem on a HIP device (there is no CPU fallback)")
-        if self.dtype not in _DT:
-            raise ValueError(f"unsupported dtype {self.dtype}")
+        if self.mat_dtype not in _DT or self.dtype not in _DT:
+            raise ValueError(f"unsupported dtype {self.mat_dtype} / {self.dtype}")
+        self.mixed = self.dtype != self.mat_dtype
+        if self.mixed and (self.mat_dtype, self.dtype) != (torch.float32, torch.float64):
+            raise ValueError("mixed precision means float32 matrix values under float64 vectors")
+        if self.mixed and (d_col is not None or d_row is not None):
+            raise ValueError("mixed precision needs the matrix entries to be float32 numbers; a Ruiz-scaled matrix is not "
+                             "(use dtype float64 with preconditioning)")
         i32 = lambda t: t.to(device=self.device, dtype=torch.int32).contiguous()
         fv = lambda t, ln: None if t is None else as_vec(t, ln, self.device, self.dtype)
         # keep every tensor the library points into alive
-        self.K = (i32(K_rows[0]), i32(K_rows[1]), K_rows[2].to(self.dtype).contiguous())
-        self.KT = (i32(KT_rows[0]), i32(KT_rows[1]), KT_rows[2].to(self.device, self.dtype).contiguous())
+        self.K = (i32(K_rows[0]), i32(K_rows[1]), K_rows[2].to(self.mat_dtype).contiguous())
+        self.KT = (i32(KT_rows[0]), i32(KT_rows[1]), KT_rows[2].to(self.device, self.mat_dtype).contiguous())
         self.c, self.l, self.u = fv(c, self.nl), fv(l, self.nl), fv(u, self.nl)
         self.q = fv(q, self.ml)
         self.d_col, self.d_row = fv(d_col, self.nl), fv(d_row, self.ml)
         self.stream = torch.cuda.current_stream(self.device)
         ptr = lambda t: None if t is None else t.data_ptr()
-        self.prob = N.PdlpProblem(_DT[self.dtype], self.device.index or 0, self.m, self.n, self.m_ineq,
+        self.prob = N.PdlpProblem(N.PDLP_MIXED if self.mixed else _DT[self.dtype], self.device.index or 0, self.m, self.n, self.m_ineq,
                                   self.rows[0], self.rows[1], self.cols[0], self.cols[1],
                                   ptr(self.K[0]), ptr(self.K[1]), ptr(self.K[2]),
                                   ptr(self.KT[0]), ptr(self.KT[1]), ptr(self.KT[2]),
@@ -102,6 +119,9 @@ class PdlpEngine:
         self.tiles = [None, None]
         self.kernels = ["csr", "csr"]
         self._maybe_attach_tiles()
+        self.delta = False
+        if self.mixed and (delta if delta is not None else os.environ.get("PDLP_DELTA", "1") != "0"):
+            self.set_delta(True)
 
     # ---- panel-tiled matrix copies (fast path for wide gathered vectors) -------------------------------
     def tile_limits(self) -> dict:
@@ -168,6 +188,23 @@ class PdlpEngine:
         self.tiles[int(transpose)] = t       # keep the arrays alive
         self.kernels[int(transpose)] = "tiled" if t.groups == 1 else f"tiled/{t.groups} groups"
 
+    def set_delta(self, on: bool):
+        """delta mode of a mixed-precision engine (include/pdlp_hip.h, pdlp_set_delta)"""
+        N.check(self.lib.pdlp_set_delta(self.h, int(bool(on))), "pdlp_set_delta")
+        self.delta = bool(on)
+
+    def delta_state(self) -> dict:
+        out = (C.c_int32 * 3)()
+        N.check(self.lib.pdlp_delta_state(self.h, out), "pdlp_delta_state")
+        return dict(delta=bool(out[0]), anchors_valid=bool(out[1]), dy_folded=bool(out[2]))
+
+    def refresh_products(self):
+        """recompute K x and K'y of the current iterate exactly (float64 accumulation): the anchors of delta mode"""
+        if self.comm is not None:
+            self._gather(N.BUF_X_CUR)
+            self._gather(N.BUF_Y_CUR)
+        N.check(self.lib.pdlp_refresh_products(self.h), "pdlp_refresh_products")
+
     def split_info(self, transpose: int) -> dict:
         """how a sharded product is split so that its local panels overlap the all-gather (zeros: not split)"""
         out = (C.c_int32 * 4)()
@@ -180,10 +217,10 @@ class PdlpEngine:
             self.lib.pdlp_destroy(h)
 
     @classmethod
-    def from_full(cls, K: CsrPair, c, q, l, u, m_ineq: int, d_col=None, d_row=None) -> "PdlpEngine":
+    def from_full(cls, K: CsrPair, c, q, l, u, m_ineq: int, d_col=None, d_row=None, vec_dtype=None, delta=None) -> "PdlpEngine":
         """single-GPU engine over a whole problem"""
         return cls(K.m, K.n, m_ineq, (K.rowptr, K.colidx, K.val), (K.t_rowptr, K.t_colidx, K.t_val), c, q, l, u,
-                   d_col=d_col, d_row=d_row)
+                   d_col=d_col, d_row=d_row, vec_dtype=vec_dtype, delta=delta)
 
     # ---- buffers ------------------------------------------------------------------------------------
     def buffer(self, which: int) -> torch.Tensor:
@@ -197,6 +234,8 @@ class PdlpEngine:
             if which in (N.BUF_RED, N.BUF_SCALARS):
                 cnt = N.NRED if which == N.BUF_RED else N.NSCAL
                 v = self.workspace[off:off + cnt * 8].view(torch.float64)
+            elif which in (N.BUF_GDX, N.BUF_GDY):
+                v = self.workspace[off:off + (self.n if which == N.BUF_GDX else self.m) * 4].view(torch.float32)
             else:
                 ln = {N.BUF_X_SUM: self.nl, N.BUF_Y_SUM: self.ml, N.BUF_DX: self.n, N.BUF_DY: self.m, N.BUF_LAM_PREV: self.nl}.get(
                     which, self.n if which <= N.BUF_X_AVG else self.m)
@@ -243,8 +282,14 @@ class PdlpEngine:
             return
         a = int(adaptive)
         lib, h, comm = self.lib, self.h, self.comm
-        xbar, red = self.buffer(N.BUF_XBAR), self.buffer(N.BUF_RED)      # fixed addresses
+        # what the other ranks need of a half-step's result: xbar and y -- or, in delta mode, the float32 differences
+        # x+ - x and y+ - y (half the bytes on the wire); all four live at fixed addresses
+        red = self.buffer(N.BUF_RED)
+        xbar = self.buffer(N.BUF_GDX if self.delta else N.BUF_XBAR)
+        gdy = self.buffer(N.BUF_GDY) if self.delta else None
         iters = int(iters)
+        if self.delta and iters > 0 and not self.delta_state()["anchors_valid"]:
+            self.refresh_products()
         for it in range(iters):
             N.check(lib.pdlp_primal_half(h, a), "pdlp_primal_half")
             # the panels of K that meet this rank's own block of xbar are multiplied (side stream) while the
@@ -254,7 +299,7 @@ class PdlpEngine:
             N.check(lib.pdlp_dual_half(h, a), "pdlp_dual_half")
             if it + 1 < iters:                             # (the new y is final: a rejected adaptive step is kept, quirk Q1)
                 N.check(lib.pdlp_primal_half_begin(h), "pdlp_primal_half_begin")
-            comm.all_gather(self.buffer(N.BUF_Y_CUR))      # the next K'y needs every rank's block of y (buffers alternate)
+            comm.all_gather(gdy if self.delta else self.buffer(N.BUF_Y_CUR))   # the next K'y needs every rank's block of y (buffers alternate)
             if adaptive:
                 N.check(lib.pdlp_adaptive_reduce(h), "pdlp_adaptive_reduce")
                 comm.all_reduce_sum(red)
@@ -271,7 +316,16 @@ class PdlpEngine:
 
     def kkt(self, which: int, omega: float, unscaled: bool = False) -> dict:
         """compute_residuals_and_duality_gap + KKT_error at CUR / AVG / PREV (helpers.py:53-108)."""
-        if self.comm is not None:
+        if self.comm is not None and self.delta:
+            # the current iterate is evaluated from the anchors (its pending dy was gathered by the iteration); a candidate
+            # from the float32 difference candidate - current, which every rank forms in full
+            if not self.delta_state()["anchors_valid"]:
+                self.refresh_products()
+            if which != N.CUR:
+                for b in (N.BUF_X_CUR, N.BUF_Y_CUR, {N.AVG: N.BUF_X_AVG, N.PREV: N.BUF_X_PREV}[which],
+                          {N.AVG: N.BUF_Y_AVG, N.PREV: N.BUF_Y_PREV}[which]):
+                    self._gather(b)
+        elif self.comm is not None:
             self._gather({N.CUR: N.BUF_X_CUR, N.AVG: N.BUF_X_AVG, N.PREV: N.BUF_X_PREV}[which])
             self._gather({N.CUR: N.BUF_Y_CUR, N.AVG: N.BUF_Y_AVG, N.PREV: N.BUF_Y_PREV}[which])
         N.check(self.lib.pdlp_kkt_local(self.h, which, int(unscaled)), "pdlp_kkt_local")

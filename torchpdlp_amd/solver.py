@@ -194,6 +194,11 @@ class PdhgDriver:
             if self.trace is not None:
                 self.trace["omega"].append(float(self.omega))
         eng.mark_restart_point()                                            # pdhg.py:63-64 of the next round
+        if getattr(eng, "delta", False):
+            # mixed precision, delta mode: the restart point's K x and K'y are recomputed exactly (float64 accumulation) -- this
+            # bounds the drift of the running products and makes the termination test below an exact evaluation
+            eng.refresh_products()
+            chosen = eng.kkt(N.CUR, self.omega)
         if chosen is None:
             chosen = eng.kkt(N.CUR, self.omega)
         # KKT_first at the restart point with the (new) omega: the residuals do not depend on omega, so
@@ -273,7 +278,7 @@ def run_pdlp(eng: PdlpEngine, max_kkt=100_000, tol=1e-4, verbose=True, restart_p
 def pdlp_algorithm(K, m_ineq, c, q, l, u, device=None, max_kkt=100_000, tol=1e-4, verbose=True, restart_period=40,
                    precondition=False, primal_update=False, adaptive=False, data_precond=None, infeasibility_detect=False,
                    infeas_tol=1e-4, time_limit=3600, time_used=0, x_init=None, y_init=None, *, b0=None, sigma=None,
-                   seed=None, trace=None, comm=None):
+                   seed=None, trace=None, comm=None, precision=None):
     """Drop-in for the reference's ``pdlp_algorithm`` (primal_dual_hybrid_gradient.py:7) on one MI355X.
 
     ``K`` may be a dense / COO torch tensor (as the reference takes), a scipy sparse matrix or a
@@ -282,6 +287,11 @@ def pdlp_algorithm(K, m_ineq, c, q, l, u, device=None, max_kkt=100_000, tol=1e-4
     ``seed`` pin the power-iteration start the reference leaves to an unseeded RNG.
     Returns ``(x, prim_obj, k, n, j, status, total_time)``; ``x`` is an (n,1) tensor and, like the
     reference's (quirk Q4), the SCALED iterate when preconditioned.
+
+    ``precision="mixed"``: float64 vectors, products and sums over a matrix held in float32 -- for tolerances below float32
+    resolution (the reference is float32 only) on matrices whose entries are float32 numbers (checked); 8 instead of 12 bytes
+    per non-zero, and the iterations run on the float32 kernels over difference vectors (delta mode, include/pdlp_hip.h).
+    ``c, q, l, u`` are taken in float64.  Not with ``precondition`` (a Ruiz-scaled matrix is not float32-valued).
 
     ``comm`` (a ``Comm``, or ``True`` for the default ``torch.distributed`` group): every rank calls with the SAME
     full problem and the same ``seed``/``b0``; each keeps its row blocks of K and K', the iterations exchange
@@ -292,6 +302,17 @@ def pdlp_algorithm(K, m_ineq, c, q, l, u, device=None, max_kkt=100_000, tol=1e-4
         device = torch.device("cuda", torch.cuda.current_device())
     Kp = CsrPair.from_any(K, device=device)
     dtype = Kp.dtype
+    vec_dtype = None
+    if precision is not None:
+        if precision != "mixed":
+            raise ValueError(f"unknown precision {precision!r}")
+        if precondition:
+            raise ValueError("precision='mixed' cannot be combined with precondition=True (use float64)")
+        from .engine import values_are_float32
+        if not (values_are_float32(Kp.val) and values_are_float32(Kp.t_val)):
+            raise ValueError("precision='mixed' needs a matrix whose entries are float32 numbers")
+        Kp = Kp.to(dtype=torch.float32)
+        dtype = vec_dtype = torch.float64
     d_col = d_row = None
     if precondition:
         if data_precond is None:
@@ -303,7 +324,7 @@ def pdlp_algorithm(K, m_ineq, c, q, l, u, device=None, max_kkt=100_000, tol=1e-4
         from .distributed import gather_solution, shard_engine
         if seed is None and b0 is None and sigma is None:
             seed = 0                                   # the ranks must draw the same power-iteration start
-        eng = shard_engine(Kp, c, q, l, u, m_ineq, comm, d_col=d_col, d_row=d_row)
+        eng = shard_engine(Kp, c, q, l, u, m_ineq, comm, d_col=d_col, d_row=d_row, vec_dtype=vec_dtype)
         if x_init is not None and y_init is not None:  # full vectors in, this rank's (zero padded) blocks on
             xi = torch.zeros(eng.n, dtype=dtype, device=device)
             yi = torch.zeros(eng.m, dtype=dtype, device=device)
@@ -320,7 +341,7 @@ def pdlp_algorithm(K, m_ineq, c, q, l, u, device=None, max_kkt=100_000, tol=1e-4
                                                   seed=seed, trace=trace, infeasibility_detect=infeasibility_detect,
                                                   infeas_tol=infeas_tol)
         return gather_solution(eng, x, Kp.n).view(-1, 1), obj, k, n, j, status, total
-    eng = PdlpEngine.from_full(Kp, c, q, l, u, m_ineq, d_col=d_col, d_row=d_row)
+    eng = PdlpEngine.from_full(Kp, c, q, l, u, m_ineq, d_col=d_col, d_row=d_row, vec_dtype=vec_dtype)
     x, obj, k, n, j, status, total = run_pdlp(eng, max_kkt, tol, verbose, restart_period, precondition, primal_update, adaptive,
                                               time_limit, time_used, x_init, y_init, b0=b0, sigma=sigma, seed=seed, trace=trace,
                                               infeasibility_detect=infeasibility_detect, infeas_tol=infeas_tol)
