@@ -101,6 +101,18 @@ typedef struct pdlp_tiles {
     const void* val;            /* [items] in the problem's precision                                      */
     const int32_t* tile_ptr;    /* [nblk*npanel + 1] item offsets, multiples of 256                        */
     const uint32_t* cnt;        /* [nblk*npanel*512*(5|3)]                                                 */
+    /* the remainder: items the tiles could not hold (more than 15 of a row in one tile, more than 255 of 64 consecutive rows,
+     * more than cap in a tile), as segments of <= 64 items of the rows that have any; rem_rows_n = 0: none */
+    int32_t rem_rows_n, rem_segs_n;
+    const int32_t* rem_rows;    /* [rem_rows_n]     rows (local) with a remainder, ascending                */
+    const int32_t* rem_rptr;    /* [rem_rows_n + 1] their segment ranges                                    */
+    const int32_t* rem_sptr;    /* [rem_segs_n + 1] item ranges of the segments                             */
+    const int32_t* rem_col;     /* [items]          column of every remainder item                          */
+    const void* rem_val;        /* [items]          value, in the precision of the matrix                   */
+    void* rem_work;             /* [rem_segs_n]     scratch, 8 bytes each                                   */
+    void* rem_extra;            /* [rows] in the working precision, ZERO-initialised: the remainder's row sums (only the rows in
+                                   rem_rows are ever written)                                               */
+    void* rem_extra_f32;        /* PDLP_MIXED only: the same in float32 for the delta-mode products          */
 } pdlp_tiles;
 
 typedef struct pdlp_solver* pdlp_handle;

@@ -1440,3 +1440,91 @@ def test_mixed_precision_solves_below_float32_resolution(golden):
     with pytest.raises(ValueError):
         tp.pdlp_algorithm(tp.CsrPair(K64.m, K64.n, K64.rowptr, K64.colidx, K64.val * (1 + 1e-9)), int(a["m_ineq"]), *vecs, DEV,
                           precision="mixed", verbose=False)
+
+
+# ---------------------------------------------------------------------------------------------------
+# tiles + remainder: matrices whose dense rows / columns / clusters break the tile format's limits
+# ---------------------------------------------------------------------------------------------------
+def _irregular_lp(m, n, per_row, seed, dense_rows=(), dense_cols=(), cluster=None, dtype=torch.float32):
+    """uniform random pattern + a few dense rows and columns (+ a dense block), as COO triplets -> scipy CSR on the host"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    rr = [np.repeat(np.arange(m), per_row)]
+    cc = [rng.integers(0, n, size=m * per_row)]
+    for r, cnt in dense_rows:
+        rr.append(np.full(cnt, r))
+        cc.append(rng.choice(n, size=cnt, replace=False))
+    for c, cnt in dense_cols:
+        rr.append(rng.choice(m, size=cnt, replace=False))
+        cc.append(np.full(cnt, c))
+    if cluster is not None:
+        r0, c0, h, w = cluster
+        keep = rng.random((h, w)) < 0.5
+        ri, ci = np.nonzero(keep)
+        rr.append(ri + r0)
+        cc.append(ci + c0)
+    rr, cc = np.concatenate(rr), np.concatenate(cc)
+    parts = [sp.csr_matrix((rng.standard_normal(rr.size), (rr, cc)), shape=(m, n))]
+    A = sum(parts[1:], parts[0]).tocsr()
+    A.sum_duplicates()
+    A.sort_indices()
+    A.data = A.data.astype(np.float32).astype(np.float64)
+    x_feas = rng.uniform(-2, 2, n)
+    m_ineq = int(0.7 * m)
+    q = A @ x_feas
+    q[:m_ineq] -= rng.uniform(0.1, 1.0, m_ineq)
+    l, u = x_feas - rng.uniform(0.5, 2, n), x_feas + rng.uniform(0.5, 2, n)
+    c = rng.standard_normal(n)
+    t = lambda v, dt=dtype: torch.tensor(np.asarray(v), dtype=dt, device=DEV)
+    K = tp.CsrPair(m, n, t(A.indptr, torch.int32), t(A.indices, torch.int32), t(A.data))
+    return A, K, (t(c), t(q), t(l), t(u)), m_ineq, (c, q, l, u)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64", "mixed"])
+def test_tiles_with_remainder_match_the_csr_kernel(monkeypatch, precision):
+    """a well-spread matrix with a dense row, two dense columns and a dense block: round 1 fell back to the CSR kernel for the whole
+    matrix; now the tiles keep what fits and a small CSR remainder carries the rest (k_rem_segments / k_rem_rows + the `extra`
+    vector in the epilogues).  Same results as the CSR kernel and the oracle, on both matrices, fused and split into panel groups."""
+    dt = torch.float32 if precision == "f32" else torch.float64
+    m, n = 150_000, 140_000
+    A, K, vecs, m_ineq, host = _irregular_lp(m, n, 12, 21, dense_rows=[(7, 30_000), (90_001, 5000)], dense_cols=[(3, 40_000), (100_000, 800)],
+                                             cluster=(50_000, 60_000, 300, 200), dtype=dt)
+    kw = {}
+    if precision == "mixed":
+        K = tp.CsrPair(K.m, K.n, K.rowptr, K.colidx, K.val.float(), K.t_rowptr, K.t_colidx, K.t_val.float())
+        kw = dict(vec_dtype=torch.float64)
+    monkeypatch.setenv("PDLP_TILED", "0")
+    e0 = tp.PdlpEngine.from_full(K, *vecs, m_ineq, **kw)
+    monkeypatch.setenv("PDLP_TILED", "1")
+    e1 = tp.PdlpEngine.from_full(K, *vecs, m_ineq, **kw)
+    assert all(t is not None for t in e1.tiles), e1.kernels
+    assert e1.tiles[0].nrem > 20_000 and e1.tiles[1].nrem > 30_000, [t.stats for t in e1.tiles]      # the dense rows of K and of K'
+    assert all(t.stats["remainder"] < 0.1 * t.stats["nnz"] for t in e1.tiles)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x0 = torch.minimum(torch.maximum(torch.randn(n, device=DEV, generator=g, dtype=e0.dtype), vecs[2].to(e0.dtype)), vecs[3].to(e0.dtype))
+    y0 = torch.randn(m, device=DEV, generator=g, dtype=e0.dtype)
+    y0[:m_ineq].clamp_(min=0)
+    tol = 3e-5 if precision == "f32" else 1e-11
+    ref_kx = A @ x0.double().cpu().numpy()
+    ref_kty = A.T @ y0.double().cpu().numpy()
+    for e in (e0, e1):
+        close(e.spmv(x0, False), ref_kx, tol)
+        close(e.spmv(y0, True), ref_kty, tol)
+    outs = []
+    for e in (e0, e1):
+        res = {}
+        for adaptive in (True, False):
+            e.set_iterate(x0, y0)
+            e.set_step(0.002, 1.2, 1.0, 0)
+            e.iterate(5, adaptive)
+            x, y = e.get_iterate(N.CUR)
+            res[adaptive] = (x.cpu().numpy(), y.cpu().numpy(), e.scalars()["eta"], e.kkt(N.CUR, 1.2))
+        outs.append(res)
+    steptol = tol if precision != "mixed" else 2e-6          # (delta mode: float32 products of the steps)
+    for adaptive in (True, False):
+        a, b = outs[0][adaptive], outs[1][adaptive]
+        close(b[0], a[0], 10 * steptol)
+        close(b[1], a[1], 10 * steptol)
+        np.testing.assert_allclose(b[2], a[2], rtol=1e-3 if precision == "f32" else 1e-5)
+        for key in ("pr", "dr", "p", "d_adj", "kkt"):
+            np.testing.assert_allclose(b[3][key], a[3][key], rtol=1e-3 if precision == "f32" else 1e-5)

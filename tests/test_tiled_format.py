@@ -60,21 +60,55 @@ def test_build_and_replay(case):
     np.testing.assert_allclose(emulate_spmv(t, x).numpy(), ref, rtol=1e-12, atol=1e-12)
 
 
-def test_not_eligible_when_a_tile_or_a_row_is_too_full():
+def _check(t, rp, ci, va, m, n, seed=5):
+    x = torch.from_numpy(np.random.default_rng(seed).standard_normal(n)).to(va.dtype)
+    ref = sp.csr_matrix((va.numpy().astype(np.float64), ci.numpy(), rp.numpy()), shape=(m, n)) @ x.numpy().astype(np.float64)
+    np.testing.assert_allclose(emulate_spmv(t, x).numpy(), ref, rtol=1e-11, atol=1e-11)
+    assert t.stats["tiled"] + t.stats["remainder"] == t.stats["nnz"] == int(rp[-1])
+    assert t.nrem == t.stats["remainder"]
+    if t.nrem:
+        sp_, rptr = t.rem_sptr.numpy(), t.rem_rptr.numpy()
+        assert sp_[0] == 0 and sp_[-1] == t.nrem and np.all(np.diff(sp_) >= 1) and np.all(np.diff(sp_) <= 64)
+        assert rptr[0] == 0 and rptr[-1] == len(sp_) - 1 and np.all(np.diff(rptr) >= 1)
+        assert np.all(np.diff(t.rem_rows.numpy()) > 0)
+
+
+def test_what_a_tile_cannot_hold_goes_to_the_remainder():
+    """round 1 gave the whole matrix back to the CSR kernel when a single tile, row or 64-row group broke a format limit; now the
+    surplus items form a small CSR remainder next to the tiles (None only when > 30 % of the items would leave them)"""
     rp, ci, va = _csr(640, 64, np.full(640, 3), 3)
-    assert build_tiles(rp, ci, va, 640, 64, lw=6, rpt=2, cap=1000) is None        # 640 rows x 3 = 1920 items in one tile
-    assert build_tiles(rp, ci, va, 640, 64, lw=6, rpt=2, cap=8000) is not None
+    t = build_tiles(rp, ci, va, 640, 64, lw=6, rpt=2, cap=1000)                    # 640 rows x 3 = 1920 items in one tile of <= 1000
+    assert t is None                                                               # ... 48 % would leave: the CSR kernel's case
+    t = build_tiles(rp, ci, va, 640, 64, lw=6, rpt=2, cap=1500, max_rest=0.4)      # every row keeps 2 of its 3
+    assert t is not None and t.stats["remainder"] == 640 and int(np.diff(t.tile_ptr.numpy()).max()) <= 1536
+    _check(t, rp, ci, va, 640, 64)
+    t = build_tiles(rp, ci, va, 640, 64, lw=6, rpt=2, cap=8000)
+    assert t is not None and t.nrem == 0
     rp, ci, va = _csr(640, 64, np.full(640, 5), 3)                                # 64 consecutive rows x 5 = 320 items of one
-    assert build_tiles(rp, ci, va, 640, 64, lw=6, rpt=2, cap=8000) is None        # tile: more than the 8-bit scan fields hold
-    assert build_tiles(rp, ci, va, 640, 64, lw=5, rpt=2, cap=8000) is not None    # (two panels: 160 per 64 rows)
-    rp, ci, va = _csr(4, 600, np.array([30, 1, 1, 1]), 4)
-    assert build_tiles(rp, ci, va, 4, 600, lw=10, rpt=2, cap=2000) is None        # 16+ entries of one row in one panel
-    t64 = build_tiles(rp, ci, va.double(), 4, 600, lw=6, rpt=2)                     # float64: 3 count words, 8192-item tiles
-    assert t64 is not None and t64.cw == 3 and t64.cap == 8192 and t64.val.dtype == torch.float64
-    x = torch.arange(600, dtype=torch.float64)
-    ref = torch.zeros(4, dtype=torch.float64).index_add_(0, torch.repeat_interleave(torch.arange(4), torch.tensor([30, 1, 1, 1])),
-                                                          va.double() * x[ci.long()])
-    np.testing.assert_allclose(emulate_spmv(t64, x).numpy(), ref.numpy(), rtol=1e-12)
+    assert build_tiles(rp, ci, va, 640, 64, lw=6, rpt=2, cap=8000) is None         # tile: more than the 8-bit scan fields hold
+    t = build_tiles(rp, ci, va, 640, 64, lw=6, rpt=2, cap=8000, max_rest=0.5)      # every row keeps 3 (192 per 64 rows), 2 go
+    assert t is not None and t.stats["remainder"] == 1280
+    _check(t, rp, ci, va, 640, 64)
+    for tile in range(t.nblk * t.npanel):
+        c = tile_row_counts(t, tile).view(NT // 64, t.rpt, 64)
+        assert int(c.sum(-1).max()) <= 255 and int(c.max()) <= 15
+    t2 = build_tiles(rp, ci, va, 640, 64, lw=5, rpt=2, cap=8000)                   # (two panels: 160 per 64 rows)
+    assert t2 is not None and t2.nrem == 0
+    # a dense row: 16+ entries of one row in one panel; and a row far longer than a remainder segment
+    lens = np.array([30, 1, 1, 400] + [2] * 2000)
+    rp, ci, va = _csr(2004, 600, lens, 4)
+    t = build_tiles(rp, ci, va, 2004, 600, lw=10, rpt=2, cap=2600)
+    assert t is not None and t.rem_rows.tolist() == [0, 3] and t.stats["remainder"] == (30 - 15) + (400 - 15)
+    assert t.rem_rptr.tolist() == [0, 1, 1 + (385 + 63) // 64]
+    _check(t, rp, ci, va, 2004, 600)
+    t64 = build_tiles(rp, ci, va.double(), 2004, 600, lw=6, rpt=2)                   # float64: 3 count words, 8192-item tiles
+    assert t64 is not None and t64.cw == 3 and t64.cap == 8192 and t64.val.dtype == torch.float64 and t64.rem_val.dtype == torch.float64
+    _check(t64, rp, ci, va.double(), 2004, 600)
+    # a banded matrix (every row's entries inside one panel): nearly everything would be remainder -> not tiled
+    m = n = 4000
+    rp = torch.arange(0, (m + 1) * 40, 40, dtype=torch.int32)
+    ci = ((torch.arange(m).view(-1, 1) + torch.arange(40).view(1, -1)) % n).to(torch.int32).sort(dim=1)[0].reshape(-1)
+    assert build_tiles(rp, ci, torch.ones(m * 40), m, n, lw=12, rpt=2) is None
 
 
 def test_no_panel_group_is_empty():
@@ -107,9 +141,9 @@ def test_panel_width_adapts_to_long_rows():
     assert choose_lw(1_000_000, 100_000_000, 1_000_000) == 14                # 100 per row over 1M columns: 6.6 at 64K, 1.6 at 16K
     m, n = 2000, 70_000
     rp, ci, va = _csr(m, n, np.full(m, 20), 11)
-    assert build_tiles(rp, ci, va, m, n, lw=16) is None                      # 64 rows x 18.7 items per panel > 255
+    assert build_tiles(rp, ci, va, m, n, lw=16) is None                      # 64 rows x 18.7 items per panel > 255: 80 % would leave
     t = build_tiles(rp, ci, va, m, n)                                        # auto: 8K-column panels
-    assert t is not None and t.lw == 13
+    assert t is not None and t.lw == 13 and t.nrem == 0
     x = torch.from_numpy(np.random.default_rng(1).standard_normal(n).astype(np.float32))
     ref = sp.csr_matrix((va.numpy().astype(np.float64), ci.numpy(), rp.numpy()), shape=(m, n)) @ x.numpy().astype(np.float64)
     np.testing.assert_allclose(emulate_spmv(t, x).numpy(), ref, rtol=1e-12, atol=1e-12)

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PDLP_LIB", os.path.join(_HERE, "libpdlp_hip.so"))   # PDLP_LIB: profiling/ablation builds
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 PDLP_F32, PDLP_F64, PDLP_MIXED = 0, 1, 2
 CUR, AVG, PREV = 0, 1, 2
 (BUF_X_CUR, BUF_X_PREV, BUF_XBAR, BUF_X_AVG, BUF_Y_CUR, BUF_Y_PREV, BUF_Y_AVG, BUF_RED, BUF_X_SUM, BUF_Y_SUM,
@@ -34,7 +34,10 @@ class PdlpProblem(C.Structure):
 class PdlpTiles(C.Structure):
     """mirror of ``struct pdlp_tiles``"""
     _fields_ = [("lw", C.c_int32), ("rpt", C.c_int32), ("cap", C.c_int32), ("nblk", C.c_int32), ("npanel", C.c_int32),
-                ("groups", C.c_int32), ("idx", C.c_void_p), ("val", C.c_void_p), ("tile_ptr", C.c_void_p), ("cnt", C.c_void_p)]
+                ("groups", C.c_int32), ("idx", C.c_void_p), ("val", C.c_void_p), ("tile_ptr", C.c_void_p), ("cnt", C.c_void_p),
+                ("rem_rows_n", C.c_int32), ("rem_segs_n", C.c_int32), ("rem_rows", C.c_void_p), ("rem_rptr", C.c_void_p),
+                ("rem_sptr", C.c_void_p), ("rem_col", C.c_void_p), ("rem_val", C.c_void_p), ("rem_work", C.c_void_p),
+                ("rem_extra", C.c_void_p), ("rem_extra_f32", C.c_void_p)]
 
 
 # every symbol include/pdlp_hip.h declares: name -> (restype, argtypes)

@@ -233,7 +233,7 @@ void launch_tiled_groups(pdlp_handle h, const Schedule& s, int rows, const void*
     StoreEpi<T> none{nullptr};
     hipLaunchKernelGGL((k_tiled_fused<T, TV, StoreEpi<T>, false>), dim3(s.t.nblk * groups), dim3(TNT), 0, stream, s.t.idx,
                        (const TV*)s.t.val, s.t.tile_ptr, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, ppg, vtotal, skip_lo,
-                       skip_len, slot0, (const T*)vin, (T*)h->rowsum, h->rs_stride, none, (double*)nullptr);
+                       skip_len, slot0, (const T*)vin, (T*)h->rowsum, h->rs_stride, (const T*)nullptr, none, (double*)nullptr);
 }
 
 // one product with K (or K') over the vector vin with the epilogue fused: T = type of vin, of the row sums and of what the
@@ -251,21 +251,31 @@ int launch_mat(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* 
     if (s.nblk == 0) return PDLP_OK;
     if (s.tiled) {
         const int rows = (int)(transpose ? h->nl : h->ml);
+        // the remainder (items the tile format could not hold) first: its row sums go to a dense vector the epilogue adds
+        const T* extra = nullptr;
+        if (s.t.rem_rows_n > 0) {
+            T* ex = (T*)(sizeof(T) == 4 && h->es == 8 ? s.t.rem_extra_f32 : s.t.rem_extra);
+            hipLaunchKernelGGL((k_rem_segments<T, TV>), dim3(grid_for((int64_t)s.t.rem_segs_n * 8)), dim3(BLOCK), 0, h->stream, s.t.rem_segs_n,
+                               s.t.rem_sptr, s.t.rem_col, (const TV*)s.t.rem_val, (const T*)vin, (T*)s.t.rem_work);
+            hipLaunchKernelGGL((k_rem_rows<T>), dim3(grid_for(s.t.rem_rows_n)), dim3(BLOCK), 0, h->stream, s.t.rem_rows_n, s.t.rem_rows,
+                               s.t.rem_rptr, (const T*)s.t.rem_work, ex);
+            extra = ex;
+        }
         if (s.t.groups == 1 && !(s.pending && h->use_split)) {
             hipLaunchKernelGGL((k_tiled_fused<T, TV, Epi, true>), dim3(s.t.nblk), dim3(TNT), 0, h->stream, s.t.idx, (const TV*)s.t.val,
                                s.t.tile_ptr, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, s.t.npanel, s.t.npanel,
-                               s.t.npanel, 0, 0, (const T*)vin, (T*)h->rowsum, h->rs_stride, epi, partials);
+                               s.t.npanel, 0, 0, (const T*)vin, (T*)h->rowsum, h->rs_stride, extra, epi, partials);
         } else if (s.pending && h->use_split) {
             // the local panels were multiplied by pdlp_*_half_begin on the side stream; now the others, then the sum
             launch_tiled_groups<T, TV>(h, s, rows, vin, h->stream, s.slotsB, s.t.npanel - (s.loc_pb - s.loc_pa), s.loc_pa,
                                    s.loc_pb - s.loc_pa, s.slotsA);
             HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_out, 0));
             hipLaunchKernelGGL((k_rowsum_epilogue<T, Epi>), dim3(grid_for(rows)), dim3(BLOCK), 0, h->stream, (const T*)h->rowsum,
-                               s.slotsA + s.slotsB, h->rs_stride, rows, epi, partials);
+                               s.slotsA + s.slotsB, h->rs_stride, rows, extra, epi, partials);
         } else {
             launch_tiled_groups<T, TV>(h, s, rows, vin, h->stream, s.t.groups, s.t.npanel, s.t.npanel, 0, 0);
             hipLaunchKernelGGL((k_rowsum_epilogue<T, Epi>), dim3(grid_for(rows)), dim3(BLOCK), 0, h->stream, (const T*)h->rowsum,
-                               s.t.groups, h->rs_stride, rows, epi, partials);
+                               s.t.groups, h->rs_stride, rows, extra, epi, partials);
         }
         HIP_TRY(hipGetLastError());
         return PDLP_OK;
@@ -307,7 +317,7 @@ template <typename T, class Epi> int primal_from_kty(pdlp_handle h, int src, Epi
 {
     if (h->nl == 0) return PDLP_OK;
     hipLaunchKernelGGL((k_rowsum_epilogue<T, Epi>), dim3(grid_for(h->nl)), dim3(BLOCK), 0, h->stream, (const T*)h->ktyb[src], 1,
-                       (int64_t)0, (int)h->nl, e, h->partA);
+                       (int64_t)0, (int)h->nl, (const T*)nullptr, e, h->partA);
     HIP_TRY(hipGetLastError());
     return PDLP_OK;
 }
@@ -491,7 +501,7 @@ template <class Epi> int delta_vector_pass(pdlp_handle h, int64_t rows, const do
 {
     if (rows == 0) return PDLP_OK;
     hipLaunchKernelGGL((k_rowsum_epilogue<double, Epi>), dim3(grid_for(rows)), dim3(BLOCK), 0, h->stream, products, 1, (int64_t)0,
-                       (int)rows, e, partials);
+                       (int)rows, (const double*)nullptr, e, partials);
     HIP_TRY(hipGetLastError());
     return PDLP_OK;
 }
@@ -507,7 +517,7 @@ template <bool ADAPT> int delta_primal_half_a(pdlp_handle h)
         h->last_gridA = h->nl > 0 ? grid_for(h->nl) : 0;
         if (h->nl == 0) return PDLP_OK;
         hipLaunchKernelGGL((k_rowsum_epilogue<float, DeltaPrimalEpi<ADAPT>>), dim3(grid_for(h->nl)), dim3(BLOCK), 0, h->stream,
-                           (const float*)nullptr, 0, (int64_t)0, (int)h->nl, e, h->partA);
+                           (const float*)nullptr, 0, (int64_t)0, (int)h->nl, (const float*)nullptr, e, h->partA);
         HIP_TRY(hipGetLastError());
         return PDLP_OK;
     }
@@ -859,7 +869,7 @@ int read_last_rowptr(const int32_t* rp, int64_t rows, int64_t* nnz, hipStream_t 
 // ================================================================================================
 extern "C" {
 
-int pdlp_abi_version(void) { return 5; }   // 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
+int pdlp_abi_version(void) { return 6; }   // 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
 
 const char* pdlp_strerror(int code)
 {
@@ -1039,6 +1049,10 @@ int pdlp_attach_tiles(pdlp_handle h, int transpose, const pdlp_tiles* t)
     if ((t->groups - 1) * ppg >= t->npanel) return PDLP_ERR_INVALID;     // every group must own at least one panel
     if (!t->idx || !t->val || !t->tile_ptr || !t->cnt) return PDLP_ERR_INVALID;
     if (((uintptr_t)t->idx & 15u) || ((uintptr_t)t->val & 15u) || ((uintptr_t)t->cnt & 3u)) return PDLP_ERR_INVALID;
+    if (t->rem_rows_n < 0 || t->rem_segs_n < t->rem_rows_n) return PDLP_ERR_INVALID;
+    if (t->rem_rows_n > 0 && (!t->rem_rows || !t->rem_rptr || !t->rem_sptr || !t->rem_col || !t->rem_val || !t->rem_work || !t->rem_extra ||
+                              (h->mixed && !t->rem_extra_f32)))
+        return PDLP_ERR_INVALID;
     s.t = *t;
     s.tiled = true;
     configure_split(h, transpose != 0);

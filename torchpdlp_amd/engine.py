@@ -182,11 +182,20 @@ class PdlpEngine:
             self.tiles[int(transpose)] = None
             self.kernels[int(transpose)] = "csr"
             return
+        rem = [0, 0] + [None] * 8
+        if t.nrem:
+            rows = self.nl if transpose else self.ml
+            t._work = torch.empty(int(t.rem_sptr.numel()) - 1, dtype=torch.float64, device=self.device)
+            t._extra = torch.zeros(rows, dtype=self.dtype, device=self.device)
+            t._extra32 = torch.zeros(rows, dtype=torch.float32, device=self.device) if self.mixed else None
+            rem = [int(t.rem_rows.numel()), int(t.rem_sptr.numel()) - 1, t.rem_rows.data_ptr(), t.rem_rptr.data_ptr(), t.rem_sptr.data_ptr(),
+                   t.rem_col.data_ptr(), t.rem_val.data_ptr(), t._work.data_ptr(), t._extra.data_ptr(),
+                   None if t._extra32 is None else t._extra32.data_ptr()]
         desc = N.PdlpTiles(t.lw, t.rpt, t.cap, t.nblk, t.npanel, t.groups, t.idx.data_ptr(), t.val.data_ptr(), t.tile_ptr.data_ptr(),
-                           t.cnt.data_ptr())
+                           t.cnt.data_ptr(), *rem)
         N.check(self.lib.pdlp_attach_tiles(self.h, int(transpose), C.byref(desc)), "pdlp_attach_tiles")
         self.tiles[int(transpose)] = t       # keep the arrays alive
-        self.kernels[int(transpose)] = "tiled" if t.groups == 1 else f"tiled/{t.groups} groups"
+        self.kernels[int(transpose)] = ("tiled" if t.groups == 1 else f"tiled/{t.groups} groups") + (f" + remainder {t.nrem}" if t.nrem else "")
 
     def set_delta(self, on: bool):
         """delta mode of a mixed-precision engine (include/pdlp_hip.h, pdlp_set_delta)"""

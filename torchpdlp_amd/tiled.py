@@ -1,4 +1,4 @@
-"""Panel-tiled storage of a CSR matrix for the fast SpMV kernel (``k_tiled_fused`` in csrc/pdlp_hip.hip).
+"""Panel-tiled storage of a CSR matrix for the fast SpMV kernel (``k_tiled_fused`` in csrc/pdlp_kernel_tiled.inc).
 
 Why (profiles/r01_microbench_gather.txt): at 10M columns the gathered vector (40 MB)
 lives in the Infinity Cache and every 4-byte gather costs a 128-byte line fill -- the plain CSR kernel
@@ -22,15 +22,23 @@ distinct 128-byte lines one wave instruction touches (about 3.4 clocks per line,
 group of 256 column-sorted items the storage order is interleaved: position ``4*lane + j`` holds sorted item
 ``64*j + lane``.  A lane's 16-byte load then yields items j = 0..3 of four different 64-item runs and gather
 instruction j covers 64 CONSECUTIVE sorted items (about 25 lines at 100 non-zeros per row) instead of 64 items
-spaced four apart (64 lines).  Bytes per non-zero: 8 + 20*512*P/nnz_per_block (the count nibbles): about 8.9 for 100 non-zeros per row at
-10M columns.
+spaced four apart (64 lines).  Bytes per non-zero: 8 + 20*512*P/nnz_per_block (the count nibbles): about 8.9 for
+100 non-zeros per row at 10M columns.
 
-A matrix is eligible when every tile holds at most ``cap`` items (16384 in float32, 8192 in float64), no
-(tile, row) more than 15 and no 64 consecutive rows more than 255 items of one tile; otherwise ``build_tiles`` returns None and the CSR kernel is used.
+Limits of the tiles proper: at most ``cap`` items per tile (16384 in float32, 8192 in float64), at most 15 items of one row
+in one tile (4-bit counts) and at most 255 items of 64 consecutive rows in one tile (the kernel scans the lanes' counts in 8-bit
+fields).  What exceeds them -- dense rows or columns of real LPs, local clusters -- goes to the *remainder* (round 2): a
+compact CSR over the rows that have such items, cut into segments of at most 64 items; ``k_rem_segments`` / ``k_rem_rows`` add
+them up in fixed order into a dense vector (zero for all other rows) that the tiled kernel's epilogue adds to the row sum.  It
+is empty for well-spread matrices such as the bench LP, which then run exactly the round-1 kernel.
+
+``build_tiles`` returns None only when tiling makes no sense: more than ``max_rest`` (30 %) of the items would leave the tiles
+-- the matrix is clustered (banded, block structured) and the CSR kernel, whose gathers are then cache friendly anyway, is the
+better kernel.
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 from typing import Optional
 
 import torch
@@ -43,6 +51,9 @@ RPT_MAX_F64 = 24     # float64: the same LDS and register budget holds half as m
 CAP_F64 = 8192
 GROUP = 256          # tiles are padded to whole groups of 4 x 64 items (interleaved, see above)
 NCU = 512            # two workgroups per CU at a time: row blocks are sized to fill whole rounds
+LMAX = 15            # items of one row in one tile (4-bit counts)
+GMAX = 255           # items of 64 consecutive rows (one i of one wave) in one tile (8-bit scan fields)
+SEG = 64             # items per remainder segment
 
 
 @dataclass
@@ -55,11 +66,18 @@ class Tiles:
     nrows: int
     ncols: int
     idx: torch.Tensor        # int32 [items]  (slot << lw) | local column
-    val: torch.Tensor        # float32 [items]
+    val: torch.Tensor        # float32 / float64 [items]
     tile_ptr: torch.Tensor   # int32 [nblk*npanel + 1], item offsets, multiples of 256
     cnt: torch.Tensor        # int32 [nblk*npanel*512*cw]: 8*cw nibbles per (tile, thread); cw = 5 (f32) or 3 (f64)
     groups: int = 1          # workgroups sharing a row block (each walks ceil(npanel/groups) panels)
     rpt_max: int = RPT_MAX   # rows per thread the kernel instantiation for this precision supports
+    # remainder: segments of <= SEG items of the rows listed in rem_rows
+    rem_rows: Optional[torch.Tensor] = None  # int32 [nr]   rows (local to this matrix) with a remainder, ascending
+    rem_rptr: Optional[torch.Tensor] = None  # int32 [nr+1] their segment ranges
+    rem_sptr: Optional[torch.Tensor] = None  # int32 [ns+1] item ranges of the segments
+    rem_col: Optional[torch.Tensor] = None   # int32 [nrem]
+    rem_val: Optional[torch.Tensor] = None   # [nrem]
+    stats: dict = field(default_factory=dict)
 
     @property
     def cw(self) -> int:
@@ -73,8 +91,13 @@ class Tiles:
     def rows_per_block(self) -> int:
         return NT * self.rpt
 
+    @property
+    def nrem(self) -> int:
+        return 0 if self.rem_col is None else int(self.rem_col.numel())
+
     def bytes(self) -> int:
-        return sum(int(t.numel()) * t.element_size() for t in (self.idx, self.val, self.tile_ptr, self.cnt))
+        ts = (self.idx, self.val, self.tile_ptr, self.cnt, self.rem_rows, self.rem_rptr, self.rem_sptr, self.rem_col, self.rem_val)
+        return sum(int(t.numel()) * t.element_size() for t in ts if t is not None)
 
 
 def rowsum_groups(rows: int) -> int:
@@ -107,7 +130,7 @@ def choose_shape(nrows: int, nnz: int, ncols: int, lw: int, cap: int = CAP, slot
     best, best_score = (1, 1), -1.0
     for rpt in range(1, rpt_max + 1):
         rb = NT * rpt
-        mean_tile = rb * per_row_panel
+        mean_tile = rb * min(per_row_panel, float(LMAX))
         if mean_tile + 6.0 * mean_tile ** 0.5 > cap and rpt > 1:      # keep 6 sigma below the LDS capacity
             break
         nblk = (nrows + rb - 1) // rb
@@ -146,11 +169,76 @@ def choose_rpt(nrows: int, nnz: int, ncols: int, lw: int, cap: int = CAP, ncu: i
     return choose_shape(nrows, nnz, ncols, lw, cap, ncu)[0]
 
 
+def _rank_in_group(key: torch.Tensor, ngroups: int):
+    """for items with integer ``key`` (any order): (rank of the item among the items of its key in input order, counts per key)"""
+    n = key.numel()
+    counts = torch.bincount(key, minlength=ngroups)
+    order = torch.argsort(key, stable=True)
+    start = torch.cumsum(counts, 0) - counts
+    rank = torch.empty(n, dtype=torch.int64, device=key.device)
+    rank[order] = torch.arange(n, device=key.device) - start[key[order]]
+    return rank, counts
+
+
+def _pack(tile: torch.Tensor, row_in_block: torch.Tensor, sortcol: torch.Tensor, low: torch.Tensor, shift: int, val: torch.Tensor,
+          ntl: int, RB: int, rpt: int, rpt_max: int, extra: Optional[torch.Tensor] = None):
+    """Lay the items of ``ntl`` tiles out the way the kernel reads them.  Items arrive in row order inside every tile (CSR
+    order); ``sortcol`` orders a tile's items for the gathers; the stored word is ``(slot << shift) | low``.
+    Returns (idx int32, val, extra int32 or None, padded tile sizes, count words int32 [ntl*512*CW])."""
+    dev = val.device
+    n = tile.numel()
+    CW = rpt_max // 8
+    tsz = torch.bincount(tile, minlength=ntl)
+    tsz_pad = (tsz + GROUP - 1) // GROUP * GROUP
+    total = int(tsz_pad.sum())
+    out_idx = torch.zeros(total, dtype=torch.int32, device=dev)
+    out_val = torch.zeros(total, dtype=val.dtype, device=dev)
+    out_extra = None if extra is None else torch.zeros(total, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(ntl * NT * CW, dtype=torch.int32, device=dev)
+    if n == 0:
+        return out_idx, out_val, out_extra, tsz_pad, cnt
+    # items of every (tile, row): 4 bits each.  Lane l of wave w owns rows w*64*rpt + i*64 + l (i < rpt) of the row block
+    c_tr = torch.bincount(tile * RB + row_in_block, minlength=ntl * RB)
+    assert int(c_tr.max()) <= LMAX
+    c_w = c_tr.view(ntl, NT // 64, rpt, 64)
+    assert int(c_w.sum(-1).max()) <= GMAX
+    nib = torch.zeros(ntl, NT, rpt_max, dtype=torch.int64, device=dev)
+    nib[:, :, :rpt] = c_w.permute(0, 1, 3, 2).reshape(ntl, NT, rpt)
+    shifts = (torch.arange(8, device=dev) * 4).view(1, 1, 1, 8)
+    cnt.copy_(_wrap_i32((nib.view(ntl, NT, CW, 8) << shifts).sum(-1).reshape(-1)))
+    del nib, c_tr, c_w
+    tstart = torch.cumsum(tsz, 0) - tsz
+    ar = torch.arange(n, device=dev)
+    # slot = rank inside the tile in row order = input order restricted to the tile
+    order1 = torch.argsort(tile, stable=True)
+    slot = torch.empty(n, dtype=torch.int64, device=dev)
+    slot[order1] = ar - tstart[tile[order1]]
+    del order1
+    # storage order: by column inside the tile
+    order2 = torch.argsort(tile * (int(sortcol.max()) + 1) + sortcol, stable=True)
+    tile_s = tile[order2]
+    packed = (slot[order2] << shift) | low[order2]
+    pstart = torch.cumsum(tsz_pad, 0) - tsz_pad
+    # padding items: value 0, slot = first unused slot of the tile, low bits 0
+    out_idx.copy_(_wrap_i32(torch.repeat_interleave(tsz << shift, tsz_pad)))
+    dest = pstart[tile_s] + (ar - tstart[tile_s])
+    out_idx[dest] = _wrap_i32(packed)
+    out_val[dest] = val[order2]
+    # interleave every 256-item group: physical 4*lane + j  <-  sorted 64*j + lane
+    out_idx.copy_(out_idx.view(-1, 4, 64).transpose(1, 2).reshape(-1))
+    out_val.copy_(out_val.view(-1, 4, 64).transpose(1, 2).reshape(-1))
+    if extra is not None:
+        out_extra[dest] = extra[order2].to(torch.int32)
+        out_extra.copy_(out_extra.view(-1, 4, 64).transpose(1, 2).reshape(-1))
+    return out_idx, out_val, out_extra, tsz_pad, cnt
+
+
 def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, nrows: int, ncols: int,
                 lw: Optional[int] = None, rpt: Optional[int] = None, cap: Optional[int] = None, max_chunk_nnz: int = 1 << 26,
-                groups: Optional[int] = None, max_groups: int = 8) -> Optional[Tiles]:
-    """CSR (any row lengths, columns sorted or not) -> Tiles, or None when not eligible.  Runs on the
-    tensors' device with torch sorts (setup cost, done once per matrix)."""
+                groups: Optional[int] = None, max_groups: int = 8, max_rest: float = 0.30) -> Optional[Tiles]:
+    """CSR (any row lengths, columns sorted or not) -> Tiles, or None when more than ``max_rest`` of the items would not
+    fit the tiles proper (a clustered matrix: the CSR kernel is the better one).  Runs on the tensors' device with torch
+    sorts (setup cost, done once per matrix)."""
     dev = val.device
     if val.dtype not in (torch.float32, torch.float64):
         return None
@@ -176,11 +264,10 @@ def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, n
         return None
     rp = rowptr.long()
     row_counts = rp[1:] - rp[:-1]
-    out_idx = torch.zeros(nnz + GROUP * NB * P, dtype=torch.int32, device=dev)
-    out_val = torch.zeros(nnz + GROUP * NB * P, dtype=val.dtype, device=dev)
+    parts_idx, parts_val, parts_cnt = [], [], []
     tile_ptr = torch.zeros(NB * P + 1, dtype=torch.int64, device=dev)
-    cnt = torch.zeros(NB * P * NT * CW, dtype=torch.int32, device=dev)
-    shifts = (torch.arange(8, device=dev) * 4).view(1, 1, 1, 8)
+    over_row, over_col, over_val = [], [], []          # what the tiles proper do not hold (row, column, value)
+    n_over = 0
     base = 0
     # chunks of whole row blocks with about max_chunk_nnz non-zeros
     blk_nnz = rp[torch.clamp(torch.arange(NB + 1, device=dev) * RB, max=nrows)].cpu().tolist()
@@ -199,62 +286,91 @@ def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, n
             v = val[a:b]
             rloc = torch.repeat_interleave(torch.arange(r_hi - r_lo, device=dev), row_counts[r_lo:r_hi])
             rblk = rloc // RB
+            rib = rloc - rblk * RB                                   # row inside its block
             tile = rblk * P + (cols >> lw)
-            tsz = torch.bincount(tile, minlength=ntl)
-            if int(tsz.max()) > cap:
-                return None
-            # items of every (tile, row): 4 bits each.  Lane l of wave w owns rows w*64*rpt + i*64 + l (i < rpt) of
-            # the row block -- for every i the 64 lanes of a wave sit on 64 consecutive rows -- and the kernel
-            # scans the lanes' counts in 8-bit fields, so 64 consecutive rows may hold at most 255 items of a tile
-            c_tr = torch.bincount(tile * RB + (rloc - rblk * RB), minlength=ntl * RB)
-            if int(c_tr.max()) > 15:
-                return None
-            c_w = c_tr.view(ntl, NT // 64, rpt, 64)
-            if int(c_w.sum(-1).max()) > 255:
-                return None
-            nib = torch.zeros(ntl, NT, rpt_max, dtype=torch.int64, device=dev)     # CW words of 8 nibbles per thread
-            nib[:, :, :rpt] = c_w.permute(0, 1, 3, 2).reshape(ntl, NT, rpt)
-            del c_tr, c_w
-            words = (nib.view(ntl, NT, CW, 8) << shifts).sum(-1)
-            cnt[t0 * NT * CW:(t0 + ntl) * NT * CW] = _wrap_i32(words.reshape(-1))
-            del nib, words
-            tstart = torch.cumsum(tsz, 0) - tsz
-            ar = torch.arange(n, device=dev)
-            # slot = rank inside the tile in (row, column) order = CSR order restricted to the tile
-            order1 = torch.argsort(tile, stable=True)
-            slot = torch.empty(n, dtype=torch.int64, device=dev)
-            slot[order1] = ar - tstart[tile[order1]]
-            del order1
-            # storage order: by column inside the tile
+            # a (tile, row) pair keeps its first `limit` items, limit <= LMAX, lowered where 64 consecutive rows (one i of one
+            # wave) would hold more than GMAX items of a tile or a tile more than `cap`; the rest goes to the remainder
+            key = tile * RB + rib
+            c_tr = torch.bincount(key, minlength=ntl * RB)
+            keep = None
+            if int(c_tr.max()) > LMAX or int(c_tr.view(ntl, NT // 64, rpt, 64).sum(-1).max()) > GMAX or \
+                    int(torch.bincount(tile, minlength=ntl).max()) > cap:
+                rank, _ = _rank_in_group(key, ntl * RB)
+                lim_g = torch.full((ntl, NT // 64, rpt), LMAX, dtype=torch.int64, device=dev)       # per (tile, wave, i)
+                c4 = c_tr.view(ntl, NT // 64, rpt, 64)
+                for L in range(LMAX, -1, -1):
+                    over = torch.clamp(c4, max=L).sum(-1) > GMAX
+                    lim_g = torch.where(over & (lim_g >= L), max(L - 1, 0), lim_g)
+                    if not bool(over.any()):
+                        break
+                lim_t = torch.full((ntl,), LMAX, dtype=torch.int64, device=dev)                     # per tile
+                for _ in range(LMAX + 1):
+                    eff = torch.minimum(lim_g, lim_t.view(ntl, 1, 1))
+                    tsz = torch.minimum(c4, eff.unsqueeze(-1)).sum((1, 2, 3))
+                    big = tsz > cap
+                    if not bool(big.any()):
+                        break
+                    lim_t = torch.where(big, lim_t - 1, lim_t)
+                eff = torch.minimum(lim_g, lim_t.view(ntl, 1, 1)).unsqueeze(-1).expand(ntl, NT // 64, rpt, 64).reshape(-1)
+                keep = rank < eff[key]
+                del lim_g, lim_t, eff, c4, rank
+            del c_tr, key
+            nd = 0 if keep is None else int((~keep).sum())
+            if nd:
+                drop = ~keep
+                n_over += nd
+                if n_over > max_rest * nnz:
+                    return None
+                over_row.append(rloc[drop] + r_lo)
+                over_col.append(cols[drop])
+                over_val.append(v[drop])
+                tile, rib, cols, v = tile[keep], rib[keep], cols[keep], v[keep]
+                del drop
+            del keep, rloc, rblk
             lcol = cols & (W - 1)
-            order2 = torch.argsort(tile * W + lcol, stable=True)
-            tile_s = tile[order2]
-            packed = (slot[order2] << lw) | lcol[order2]
-            tsz_pad = (tsz + GROUP - 1) // GROUP * GROUP
-            pstart = torch.cumsum(tsz_pad, 0) - tsz_pad
-            total = int(tsz_pad.sum())
-            seg_i = out_idx[base:base + total]
-            seg_v = out_val[base:base + total]
-            # padding items: value 0, slot = first unused slot of the tile, local column 0
-            seg_i.copy_(_wrap_i32(torch.repeat_interleave(tsz << lw, tsz_pad)))
-            dest = pstart[tile_s] + (ar - tstart[tile_s])
-            seg_i[dest] = _wrap_i32(packed)
-            seg_v[dest] = v[order2]
-            # interleave every 256-item group: physical 4*lane + j  <-  sorted 64*j + lane
-            seg_i.copy_(seg_i.view(-1, 4, 64).transpose(1, 2).reshape(-1))
-            seg_v.copy_(seg_v.view(-1, 4, 64).transpose(1, 2).reshape(-1))
-            tile_ptr[t0:t0 + ntl] = base + pstart
-            base += total
+            p_idx, p_val, _, tsz_pad, p_cnt = _pack(tile, rib, lcol, lcol, lw, v, ntl, RB, rpt, rpt_max)
+            parts_idx.append(p_idx)
+            parts_val.append(p_val)
+            parts_cnt.append(p_cnt)
+            tile_ptr[t0:t0 + ntl] = base + torch.cumsum(tsz_pad, 0) - tsz_pad
+            base += int(tsz_pad.sum())
         else:
+            parts_cnt.append(torch.zeros(ntl * NT * CW, dtype=torch.int32, device=dev))
             tile_ptr[t0:t0 + ntl] = base
         b_lo = b_hi
     tile_ptr[NB * P] = base
-    return Tiles(lw, rpt, cap, NB, P, nrows, ncols, out_idx[:base].contiguous(), out_val[:base].contiguous(),
-                 tile_ptr.to(torch.int32), cnt, normalize_groups(groups, P, max(1, int(max_groups))), rpt_max)
+    cat = lambda parts, dt: (parts[0] if len(parts) == 1 else torch.cat(parts)) if parts else torch.zeros(0, dtype=dt, device=dev)
+    idx_all, val_all = cat(parts_idx, torch.int32), cat(parts_val, val.dtype)
+    del parts_idx, parts_val
+    t = Tiles(lw, rpt, cap, NB, P, nrows, ncols, idx_all, val_all, tile_ptr.to(torch.int32), cat(parts_cnt, torch.int32),
+              normalize_groups(groups, P, max(1, int(max_groups))), rpt_max)
+    t.stats = dict(nnz=nnz, tiled=nnz - n_over, remainder=0)
+    if n_over == 0:
+        return t
+    orow, ocol, oval = torch.cat(over_row), torch.cat(over_col), torch.cat(over_val)
+    del over_row, over_col, over_val
+    # ---- the remainder: segments of <= SEG items, row by row (the items arrive in row order)
+    nrem = int(orow.numel())
+    t.stats["remainder"] = nrem
+    if nrem > 0:
+        rrow, rcol, rval = orow, ocol, oval
+        rows_u, per_row = torch.unique_consecutive(rrow, return_counts=True)
+        segs_per_row = (per_row + SEG - 1) // SEG
+        rptr = torch.zeros(rows_u.numel() + 1, dtype=torch.int64, device=dev)
+        rptr[1:] = torch.cumsum(segs_per_row, 0)
+        ns = int(rptr[-1])
+        row_start = torch.cumsum(per_row, 0) - per_row
+        seg_row = torch.repeat_interleave(torch.arange(rows_u.numel(), device=dev), segs_per_row)
+        seg_j = torch.arange(ns, device=dev) - rptr[:-1][seg_row]
+        s0 = row_start[seg_row] + SEG * seg_j
+        sptr = torch.cat([s0, torch.tensor([nrem], device=dev)])
+        t.rem_rows, t.rem_rptr, t.rem_sptr = rows_u.to(torch.int32), rptr.to(torch.int32), sptr.to(torch.int32)
+        t.rem_col, t.rem_val = rcol.to(torch.int32).contiguous(), rval.contiguous()
+    return t
 
 
 def tile_row_counts(t: Tiles, tile: int) -> torch.Tensor:
-    """items of each of the tile's 1024*rpt rows (unpacks the nibbles)"""
+    """items of each of the tile's 512*rpt rows (unpacks the nibbles)"""
     CW = t.cw
     w = t.cnt[tile * NT * CW:(tile + 1) * NT * CW].long() & 0xFFFFFFFF
     shifts = (torch.arange(8, device=w.device) * 4).view(1, 1, 8)
@@ -264,25 +380,34 @@ def tile_row_counts(t: Tiles, tile: int) -> torch.Tensor:
 
 
 def emulate_spmv(t: Tiles, x: torch.Tensor) -> torch.Tensor:
-    """What the kernel computes, step by step, in torch on any device (tests only: pass 1 writes the
-    products to their row-order slots, pass 2 sums each row's segment)."""
+    """What the kernels compute, step by step, in torch on any device (tests only: pass 1 writes the
+    products to their row-order slots, pass 2 sums each row's segment; then the remainder)."""
     RB, W = t.rows_per_block, 1 << t.lw
     y = torch.zeros(t.nblk * RB, dtype=torch.float64, device=x.device)
+    xd = x.double()
+
+    def one(slots, val, cols, i0, i1, counts, b):
+        if i1 == i0:
+            return
+        prod = torch.zeros(t.cap + 8, dtype=torch.float64, device=x.device)
+        prod[slots] = val[i0:i1].double() * xd[cols]
+        ends = torch.cumsum(counts, 0)
+        csum = torch.cat([torch.zeros(1, dtype=torch.float64, device=x.device), torch.cumsum(prod[:int(ends[-1])], 0)])
+        y[b * RB:(b + 1) * RB] += csum[ends] - csum[ends - counts]
+
     idx = t.idx.long() & 0xFFFFFFFF
     tp = t.tile_ptr.long().tolist()
     for b in range(t.nblk):
         for p in range(t.npanel):
             tile = b * t.npanel + p
             i0, i1 = tp[tile], tp[tile + 1]
-            if i1 == i0:
-                continue
             pk = idx[i0:i1]
-            prod = torch.zeros(t.cap + 8, dtype=torch.float64, device=x.device)
-            xin = x[p * W:(p + 1) * W].double()
-            lcol = pk & (W - 1)
-            prod[pk >> t.lw] = t.val[i0:i1].double() * xin[lcol]
-            c = tile_row_counts(t, tile)
-            ends = torch.cumsum(c, 0)
-            csum = torch.cat([torch.zeros(1, dtype=torch.float64, device=x.device), torch.cumsum(prod[:int(ends[-1])], 0)])
-            y[b * RB:(b + 1) * RB] += csum[ends] - csum[ends - c]
+            one(pk >> t.lw, t.val, torch.clamp(p * W + (pk & (W - 1)), max=t.ncols - 1), i0, i1, tile_row_counts(t, tile), b)
+    if t.nrem:
+        sp, rptr = t.rem_sptr.long(), t.rem_rptr.long().tolist()
+        prod = t.rem_val.double() * xd[t.rem_col.long()]
+        cs = torch.cat([torch.zeros(1, dtype=torch.float64, device=x.device), torch.cumsum(prod, 0)])
+        seg = cs[sp[1:]] - cs[sp[:-1]]
+        for i, r in enumerate(t.rem_rows.tolist()):
+            y[r] += seg[rptr[i]:rptr[i + 1]].sum()
     return y[:t.nrows]
