@@ -102,7 +102,7 @@ typedef struct pdlp_tiles {
     const int32_t* tile_ptr;    /* [nblk*npanel + 1] item offsets, multiples of 256                        */
     const uint32_t* cnt;        /* [nblk*npanel*512*(5|3)]                                                 */
     /* the remainder: items the tiles could not hold (more than 15 of a row in one tile, more than 255 of 64 consecutive rows,
-     * more than cap in a tile), as segments of <= 64 items of the rows that have any; rem_rows_n = 0: none */
+     * more than cap in a tile), as segments of <= 512 items of the rows that have any; rem_rows_n = 0: none */
     int32_t rem_rows_n, rem_segs_n;
     const int32_t* rem_rows;    /* [rem_rows_n]     rows (local) with a remainder, ascending                */
     const int32_t* rem_rptr;    /* [rem_rows_n + 1] their segment ranges                                    */

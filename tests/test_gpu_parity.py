@@ -1274,8 +1274,8 @@ def test_config3_one_eighth_shard_of_10Mx10M(monkeypatch):
             mine = xbar[c0:c1].clone()
             if split:
                 N.check(lib.pdlp_dual_half_begin(h, adaptive))  # local panels of K against this rank's own block of xbar
-            xbar.copy_(xbar_others)                             # ... the other ranks' blocks arrive
-            xbar[c0:c1] = mine
+            xbar[:c0] = xbar_others[:c0]                        # ... the other ranks' blocks arrive (the own block is being read
+            xbar[c1:] = xbar_others[c1:]                        #     by the early product on the library's side stream: hands off)
             N.check(lib.pdlp_dual_half(h, adaptive))
             x, y = eng.get_iterate(N.CUR)
             red = None

@@ -68,7 +68,7 @@ def _check(t, rp, ci, va, m, n, seed=5):
     assert t.nrem == t.stats["remainder"]
     if t.nrem:
         sp_, rptr = t.rem_sptr.numpy(), t.rem_rptr.numpy()
-        assert sp_[0] == 0 and sp_[-1] == t.nrem and np.all(np.diff(sp_) >= 1) and np.all(np.diff(sp_) <= 64)
+        assert sp_[0] == 0 and sp_[-1] == t.nrem and np.all(np.diff(sp_) >= 1) and np.all(np.diff(sp_) <= 512)
         assert rptr[0] == 0 and rptr[-1] == len(sp_) - 1 and np.all(np.diff(rptr) >= 1)
         assert np.all(np.diff(t.rem_rows.numpy()) > 0)
 
@@ -99,7 +99,7 @@ def test_what_a_tile_cannot_hold_goes_to_the_remainder():
     rp, ci, va = _csr(2004, 600, lens, 4)
     t = build_tiles(rp, ci, va, 2004, 600, lw=10, rpt=2, cap=2600)
     assert t is not None and t.rem_rows.tolist() == [0, 3] and t.stats["remainder"] == (30 - 15) + (400 - 15)
-    assert t.rem_rptr.tolist() == [0, 1, 1 + (385 + 63) // 64]
+    assert t.rem_rptr.tolist() == [0, 1, 2]
     _check(t, rp, ci, va, 2004, 600)
     t64 = build_tiles(rp, ci, va.double(), 2004, 600, lw=6, rpt=2)                   # float64: 3 count words, 8192-item tiles
     assert t64 is not None and t64.cw == 3 and t64.cap == 8192 and t64.val.dtype == torch.float64 and t64.rem_val.dtype == torch.float64

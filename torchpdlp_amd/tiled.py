@@ -28,7 +28,7 @@ spaced four apart (64 lines).  Bytes per non-zero: 8 + 20*512*P/nnz_per_block (t
 Limits of the tiles proper: at most ``cap`` items per tile (16384 in float32, 8192 in float64), at most 15 items of one row
 in one tile (4-bit counts) and at most 255 items of 64 consecutive rows in one tile (the kernel scans the lanes' counts in 8-bit
 fields).  What exceeds them -- dense rows or columns of real LPs, local clusters -- goes to the *remainder* (round 2): a
-compact CSR over the rows that have such items, cut into segments of at most 64 items; ``k_rem_segments`` / ``k_rem_rows`` add
+compact CSR over the rows that have such items, cut into segments of at most 512 items; ``k_rem_segments`` / ``k_rem_rows`` add
 them up in fixed order into a dense vector (zero for all other rows) that the tiled kernel's epilogue adds to the row sum.  It
 is empty for well-spread matrices such as the bench LP, which then run exactly the round-1 kernel.
 
@@ -53,7 +53,7 @@ GROUP = 256          # tiles are padded to whole groups of 4 x 64 items (interle
 NCU = 512            # two workgroups per CU at a time: row blocks are sized to fill whole rounds
 LMAX = 15            # items of one row in one tile (4-bit counts)
 GMAX = 255           # items of 64 consecutive rows (one i of one wave) in one tile (8-bit scan fields)
-SEG = 64             # items per remainder segment
+SEG = 512            # items per remainder segment (one wave: 8 per lane)
 
 
 @dataclass
