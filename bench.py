@@ -14,7 +14,7 @@ cost of the (steps/40 - checks held) missing or surplus checks is added at the m
 For steps a multiple of 40 that is steps / elapsed exactly.  All three raw numbers are in "timing".
 The LP is resident in HBM before the clock starts.  Default workload = the one the metric is quoted
 on: 10M x 10M, density 1e-5 (100 non-zeros per row), float32 like the reference; it fits one GPU.
-With N > 1 the same instance is sharded (row blocks of K and K'), so scaling is strong.
+With N > 1 the same instance is sharded (row blocks of K and K'; every rank generates its own shard), so scaling is strong.
 
 Also reports, in the same JSON line:
   roofline     algorithmic HBM bytes of the dominant kernel per launch / its mean duration (HIP events)
@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 
 import torchpdlp_amd as tp                                     # noqa: E402
 from torchpdlp_amd import _native as N                         # noqa: E402
-from torchpdlp_amd.distributed import shard_engine             # noqa: E402
+from torchpdlp_amd.distributed import gen_lp_shard             # noqa: E402
 from torchpdlp_amd.solver import PdhgDriver, estimate_sigma    # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
@@ -221,13 +221,20 @@ def main():
     adaptive = args.mode == "adaptive"
 
     t_setup = time.time()
-    lp = tp.gen_lp(args.n, m, args.nnz_per_row, seed=0, device=dev, dtype=dt)
-    K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
-    nnz = K.nnz
-    eng = shard_engine(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq, comm)
-    if comm is not None:            # every rank generated the whole seeded instance; keep only the block
+    if comm is None:
+        lp = tp.gen_lp(args.n, m, args.nnz_per_row, seed=0, device=dev, dtype=dt)
+        K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
+        nnz = K.nnz
+        eng = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
         del K, lp
-        torch.cuda.empty_cache()
+    else:
+        # the same seeded instance, but every rank generates only its own rows of K and receives its rows of K' through the
+        # distributed transpose: no rank ever holds the whole LP (SURVEY 8d cfg 4)
+        eng = gen_lp_shard(args.n, m, args.nnz_per_row, 0, comm, dev, dt)
+        tn = torch.tensor([eng.nnz_local], dtype=torch.int64, device=dev)
+        comm.all_reduce_sum(tn)
+        nnz = int(tn)
+    torch.cuda.empty_cache()
     drv = PdhgDriver(eng, restart_period=40, primal_update=True, adaptive=adaptive, tol=1e-4)
     sigma = estimate_sigma(eng, power_iters=20, seed=0)
     drv.start(sigma)

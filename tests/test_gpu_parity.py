@@ -1241,6 +1241,7 @@ def test_config3_one_eighth_shard_of_10Mx10M(monkeypatch):
     K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
     from torchpdlp_amd.distributed import shard_arrays
     args = shard_arrays(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq, rank, W)
+    args.pop("part")
     r0, r1 = args["rows"]
     c0, c1 = args["cols"]
     assert (r0, r1, c0, c1) == (3_750_000, 5_000_000, 3_750_000, 5_000_000)

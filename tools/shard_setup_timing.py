@@ -35,6 +35,7 @@ for W in worlds:
         t3 = t2
     else:
         parts = shard_arrays(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq, 0, W)
+        parts.pop("part")
         sync(); t3 = time.time()
         eng = tp.PdlpEngine(comm=FakeComm(W), **parts)
     sync(); t4 = time.time()

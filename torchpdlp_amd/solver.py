@@ -226,6 +226,11 @@ def estimate_sigma(eng: PdlpEngine, b0=None, power_iters=100, seed=None) -> floa
         b0 = torch.randn(eng.n, generator=g, dtype=torch.float32).to(eng.device)
         if eng.comm is not None:
             eng.comm.dist.broadcast(b0, 0, group=eng.comm.group)
+            part = getattr(eng, "part", None)
+            if part is not None:                      # (drawn in the padded layout: padding variables have empty columns --
+                keep = torch.zeros(eng.n, dtype=torch.bool, device=eng.device)       # zero their entries so that the start
+                keep[part.col_map(eng.device)] = True                                # vector is one of the original LP)
+                b0 = b0 * keep
     return eng.power_iteration(b0, power_iters)
 
 
@@ -324,17 +329,13 @@ def pdlp_algorithm(K, m_ineq, c, q, l, u, device=None, max_kkt=100_000, tol=1e-4
         from .distributed import gather_solution, shard_engine
         if seed is None and b0 is None and sigma is None:
             seed = 0                                   # the ranks must draw the same power-iteration start
-        eng = shard_engine(Kp, c, q, l, u, m_ineq, comm, d_col=d_col, d_row=d_row, vec_dtype=vec_dtype)
-        if x_init is not None and y_init is not None:  # full vectors in, this rank's (zero padded) blocks on
-            xi = torch.zeros(eng.n, dtype=dtype, device=device)
-            yi = torch.zeros(eng.m, dtype=dtype, device=device)
-            xi[:Kp.n] = as_vec(x_init, Kp.n, device, dtype)
-            yi[:Kp.m] = as_vec(y_init, Kp.m, device, dtype)
+        eng = shard_engine(Kp, c, q, l, u, m_ineq, comm, d_col=d_col, d_row=d_row, vec_dtype=vec_dtype)    # blocks balanced by non-zeros
+        if x_init is not None and y_init is not None:  # full vectors in, this rank's blocks of the padded layout on
+            xi = eng.part.pad_cols(as_vec(x_init, Kp.n, device, dtype))
+            yi = eng.part.pad_rows(as_vec(y_init, Kp.m, device, dtype))
             x_init, y_init = xi[eng.cols[0]:eng.cols[1]], yi[eng.rows[0]:eng.rows[1]]
         if b0 is not None:
-            bp = torch.zeros(eng.n, dtype=torch.float32, device=device)
-            bp[:Kp.n] = as_vec(b0, Kp.n, device, torch.float32)
-            b0 = bp
+            b0 = eng.part.pad_cols(as_vec(b0, Kp.n, device, torch.float32))
         verbose = verbose and comm.rank == 0
         x, obj, k, n, j, status, total = run_pdlp(eng, max_kkt, tol, verbose, restart_period, precondition, primal_update,
                                                   adaptive, time_limit, time_used, x_init, y_init, b0=b0, sigma=sigma,

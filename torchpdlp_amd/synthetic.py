@@ -6,7 +6,9 @@ The LP form is the reference's (``/root/reference/PDLP/util.py:76-84``)::
 
 Two recipes:
 
-``box``    the distribution of the reference's own generator
+``box``    (every array is seeded per 2^16-row chunk: ``box_rows`` / ``box_vectors`` let one rank of a sharded run generate
+           exactly its rows of the same instance -- ``distributed.gen_lp_shard``)
+           the distribution of the reference's own generator
            (``/root/reference/Packages/generate_feasible_lp.py:18-41``), restated for a
            row-regular sparse matrix: every row has ``nnz_per_row`` uniformly random
            columns with U[0,1) values, ``x_feas ~ U(-10,10)``, inequality rows get a
@@ -81,6 +83,51 @@ def _regular_rmatvec(col, val, y, m, n, k, chunk_rows):
     return out
 
 
+CHUNK_ROWS = 1 << 16
+
+
+def _chunk_gen(seed: int, stream: int, chunk: int, device) -> torch.Generator:
+    """the generator of one 2^16-row chunk of one random array of the "box" recipe: every chunk can be produced on its own,
+    so a rank of a sharded run generates exactly its rows of the very instance a single process generates"""
+    g = torch.Generator(device=device)
+    g.manual_seed((int(seed) * 1_000_003 + 7919 * int(stream) + int(chunk)) % (2 ** 63 - 1))
+    return g
+
+
+def box_rows(n: int, k: int, seed: int, r_lo: int, r_hi: int, device, dtype=torch.float32):
+    """rows [r_lo, r_hi) of the "box" recipe's matrix: (column indices int32 [rows*k] sorted inside each row, values [rows*k])"""
+    device = torch.device(device)
+    cols, vals = [], []
+    for ch in range(r_lo // CHUNK_ROWS, (max(r_hi, r_lo + 1) - 1) // CHUNK_ROWS + 1):
+        c0 = ch * CHUNK_ROWS
+        rows = CHUNK_ROWS
+        blk = torch.randint(0, n, (rows, k), generator=_chunk_gen(seed, 1, ch, device), device=device, dtype=torch.int32)
+        blk, _ = torch.sort(blk, dim=1)
+        v = torch.rand(rows * k, generator=_chunk_gen(seed, 2, ch, device), device=device, dtype=torch.float32).view(rows, k)
+        a, b = max(r_lo, c0) - c0, min(r_hi, c0 + rows) - c0
+        if b > a:
+            cols.append(blk[a:b].reshape(-1))
+            vals.append(v[a:b].reshape(-1).to(dtype))
+        del blk, v
+    if not cols:
+        return torch.zeros(0, dtype=torch.int32, device=device), torch.zeros(0, dtype=dtype, device=device)
+    return torch.cat(cols), torch.cat(vals)
+
+
+def box_vectors(n: int, m: int, seed: int, device, ineq_frac: float = 0.8) -> dict:
+    """the vectors of the "box" recipe in float64 (x_feas, slack of the inequality rows, l, u, c), each from its own seed"""
+    device = torch.device(device)
+    m_ineq = int(round(ineq_frac * m))
+
+    def U(stream, count, lo, hi):
+        return torch.rand(count, generator=_chunk_gen(seed, stream, 0, device), device=device, dtype=torch.float64) * (hi - lo) + lo
+
+    x_feas = U(3, n, -10.0, 10.0)
+    return dict(m_ineq=m_ineq, x_feas=x_feas, slack=U(4, m_ineq, 0.1, 5.0),
+                l=torch.clamp(x_feas - U(5, n, 1.0, 5.0), min=-1e4), u=torch.clamp(x_feas + U(6, n, 1.0, 5.0), max=1e4),
+                c=torch.randn(n, generator=_chunk_gen(seed, 7, 0, device), device=device, dtype=torch.float64))
+
+
 def gen_lp(n: int, m: int, nnz_per_row: int, seed: int = 0, device="cpu",
            dtype=torch.float32, ineq_frac: float = 0.8, recipe: str = "box",
            chunk_rows: int = 1 << 20) -> SyntheticLP:
@@ -93,26 +140,20 @@ def gen_lp(n: int, m: int, nnz_per_row: int, seed: int = 0, device="cpu",
     def U(shape, lo, hi):
         return torch.rand(shape, generator=gen, device=device, dtype=torch.float64) * (hi - lo) + lo
 
-    col = _regular_pattern(m, n, k, gen, device, chunk_rows)
-    rowptr = torch.arange(0, (m + 1) * k, k, dtype=torch.int64, device=device).to(torch.int32)
-
     if recipe == "box":
-        val = torch.empty(m * k, dtype=dtype, device=device)
-        for r0 in range(0, m * k, chunk_rows * 8):
-            r1 = min(m * k, r0 + chunk_rows * 8)
-            val[r0:r1] = torch.rand(r1 - r0, generator=gen, device=device, dtype=torch.float32).to(dtype)
-        x_feas = U(n, -10.0, 10.0)
-        kx = _regular_matvec(col, val, x_feas, m, k, chunk_rows)
+        vec = box_vectors(n, m, seed, device, ineq_frac)
+        col, val = box_rows(n, k, seed, 0, m, device, dtype)
+        rowptr = torch.arange(0, (m + 1) * k, k, dtype=torch.int64, device=device).to(torch.int32)
+        kx = _regular_matvec(col, val, vec["x_feas"], m, k, chunk_rows)
         q = kx.clone()
-        q[:m_ineq] -= U(m_ineq, 0.1, 5.0)
-        l = torch.clamp(x_feas - U(n, 1.0, 5.0), min=-1e4)
-        u = torch.clamp(x_feas + U(n, 1.0, 5.0), max=1e4)
-        c = torch.randn(n, generator=gen, device=device, dtype=torch.float64)
-        return SyntheticLP(m, n, m_ineq, rowptr, col, val, c.to(dtype), q.to(dtype),
-                           l.to(dtype), u.to(dtype), x_feas.to(dtype))
+        q[:m_ineq] -= vec["slack"]
+        return SyntheticLP(m, n, m_ineq, rowptr, col, val, vec["c"].to(dtype), q.to(dtype), vec["l"].to(dtype), vec["u"].to(dtype),
+                           vec["x_feas"].to(dtype))
 
     if recipe != "mixed":
         raise ValueError(f"unknown recipe {recipe!r}")
+    col = _regular_pattern(m, n, k, gen, device, chunk_rows)
+    rowptr = torch.arange(0, (m + 1) * k, k, dtype=torch.int64, device=device).to(torch.int32)
 
     val = torch.randn(m * k, generator=gen, device=device, dtype=torch.float64).to(dtype)
     # bound classes: 0 boxed, 1 lower only, 2 upper only, 3 free
