@@ -33,6 +33,7 @@ extern "C" {
 #define PDLP_ERR_INVALID (-1)      /* bad argument / inconsistent sizes            */
 #define PDLP_ERR_WORKSPACE (-2)    /* workspace too small or misaligned            */
 #define PDLP_ERR_STATE (-3)        /* call sequence violated                       */
+#define PDLP_ERR_COMM (-4)         /* RCCL could not be loaded, or a collective failed */
 #define PDLP_ERR_HIP_BASE (-1000)  /* -(1000 + hipError_t) for HIP runtime errors  */
 
 /* working precision: PDLP_F32 / PDLP_F64 = every vector and matrix value in that type; PDLP_MIXED = float32 matrix values
@@ -179,12 +180,27 @@ int pdlp_adaptive_reduce(pdlp_handle h);
 /* adaptive rule, part 2: eta_bar, eta', accept/reject, eta <- eta', weight of this iterate in the
  * average, k <- k+1 -- step.py:99-115 incl. the single-trial quirk, pdhg.py:107-112 */
 int pdlp_adaptive_update(pdlp_handle h);
-/* `iters` whole iterations without host synchronisation (single-rank problems only):
- * primal half, dual half and, when adaptive, the step-size rule.  pdhg.py:76-112 */
+/* `iters` whole iterations without host synchronisation: primal half, dual half and, when adaptive, the step-size rule
+ * (pdhg.py:76-112).  Single-rank problems, or sharded ones after pdlp_comm_init (the exchange then happens inside). */
 int pdlp_iterate(pdlp_handle h, int iters, int adaptive);
 /* fixed step, multi-rank driver: eta_total += eta and k += 1, `iters` times (pdhg.py:76,109);
  * pdlp_iterate does this itself */
 int pdlp_fixed_advance(pdlp_handle h, int iters);
+
+/* ---- sharded problems: the exchange inside the library (RCCL over xGMI) ------------------------------------------------
+ * One process per GPU; rank r owns block r of the constraints and of the variables (equal, padded blocks -- the layout of
+ * torchpdlp_amd/distributed.py).  The reference is single-device, so these have no counterpart there; SURVEY.md 8b sketched
+ * them as pdlp_create_sharded(..., ncclComm_t, rank, nranks).  RCCL is resolved with dlopen on first use (rccl_path: the
+ * librccl.so the process already has loaded, e.g. PyTorch's; NULL = search the default names), so single-GPU use never needs it.
+ * pdlp_comm_unique_id: rank 0 creates the id, the caller broadcasts its 128 bytes to all ranks (any transport).
+ * pdlp_comm_init: ncclCommInitRank on the handle's device.  From then on pdlp_iterate runs whole sharded iterations --
+ *   half-steps, the all-gathers of xbar and y (float32 differences in delta mode) overlapped with the local panels' products,
+ *   and the 3-double all-reduce of the step-size rule -- on the handle's stream with no host work in between.
+ * pdlp_comm_all_gather / pdlp_comm_all_reduce_red: the same collectives for the caller-driven parts (KKT passes, set-up). */
+int pdlp_comm_unique_id(const char* rccl_path, void* id128);
+int pdlp_comm_init(pdlp_handle h, const char* rccl_path, const void* id128, int rank, int nranks);
+int pdlp_comm_all_gather(pdlp_handle h, int which /* PDLP_BUF_* of a full-length vector */);
+int pdlp_comm_all_reduce_red(pdlp_handle h);
 
 /* ---- delta mode (PDLP_MIXED handles; no counterpart in the float32 reference) --------------------------------------
  * on != 0: from now on every product of an iteration and of a KKT pass runs on the FLOAT32 kernels over a float32 difference

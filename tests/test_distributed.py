@@ -227,14 +227,13 @@ def _gpu_worker(rank, world, port, ret):
         dev = torch.device("cuda", 0)
         lp, K = _lp(dev)
         comm = tp.Comm()
-        b0 = torch.randn(padded(lp.n, world), generator=torch.Generator().manual_seed(9)).to(dev)
-        b0[lp.n:] = 0
+        b0 = torch.randn(lp.n, generator=torch.Generator().manual_seed(9)).to(dev)      # (original variable order)
         out = {}
         for adaptive in (False, True):
-            eng = shard_engine(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq, comm)
+            eng = shard_engine(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq, comm)                  # blocks balanced by non-zeros
             trace = dict(kkt=[], omega=[], restarts=[])
-            x, obj, k, n, j, status, _ = run_pdlp(eng, tol=1e-4, verbose=False, primal_update=True, adaptive=adaptive, b0=b0,
-                                                  trace=trace)
+            x, obj, k, n, j, status, _ = run_pdlp(eng, tol=1e-4, verbose=False, primal_update=True, adaptive=adaptive,
+                                                  b0=eng.part.pad_cols(b0), trace=trace)
             xf = gather_solution(eng, x, lp.n)
             out[adaptive] = (xf.cpu(), obj, k, n, j, status, trace)
             del eng
@@ -243,7 +242,7 @@ def _gpu_worker(rank, world, port, ret):
                 eng1 = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
                 tr1 = dict(kkt=[], omega=[], restarts=[])
                 x1, obj1, k1, n1, j1, st1, _ = run_pdlp(eng1, tol=1e-4, verbose=False, primal_update=True, adaptive=adaptive,
-                                                        b0=b0[:lp.n], trace=tr1)
+                                                        b0=b0, trace=tr1)
                 xf, obj, k, n, j, status, trace = out[adaptive]
                 assert status == st1 == "Solved"
                 assert abs(obj - lp.opt_obj) <= 2e-3 * (1 + abs(lp.opt_obj))
@@ -280,6 +279,16 @@ def _gpu_worker(rank, world, port, ret):
         assert abs(res.objective - lp.opt_obj) <= 2e-3 * (1 + abs(lp.opt_obj))
         xs = res.x.view(-1)
         assert float((lp.c.view(-1).to(xs) * xs).sum()) == pytest.approx(res.objective, rel=1e-3, abs=1e-3)
+        # mixed precision + delta mode, sharded: the ranks exchange the float32 differences x+ - x and y+ - y instead of xbar and y
+        v64 = [t.double() for t in (lp.c, lp.q, lp.l, lp.u)]
+        xm, objm, km, nm, jm, stm, _ = tp.pdlp_algorithm(K, lp.m_ineq, *v64, dev, tol=1e-6, verbose=False, adaptive=True, primal_update=True,
+                                                         seed=2, precision="mixed", comm=comm, max_kkt=400_000)
+        assert stm == "Solved" and xm.dtype == torch.float64 and xm.shape == (lp.n, 1)
+        assert abs(objm - lp.opt_obj) <= 3e-5 * (1 + abs(lp.opt_obj))              # (float32 could not certify 1e-6)
+        if rank == 0:
+            x1, obj1, k1, n1, j1, st1, _ = tp.pdlp_algorithm(K, lp.m_ineq, *v64, dev, tol=1e-6, verbose=False, adaptive=True,
+                                                             primal_update=True, seed=2, precision="mixed")
+            assert st1 == "Solved" and abs(obj1 - objm) <= 3e-5 * (1 + abs(obj1)) and 0.3 * k1 <= km <= 3 * k1
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()
@@ -319,17 +328,15 @@ def _gpu_split_worker(rank, world, port, ret):
         res = {}
         for adaptive in (True, False):
             g = torch.Generator().manual_seed(3)
-            x0 = torch.randn(eng.n, generator=g).to(dev)
-            y0 = torch.randn(eng.m, generator=g).to(dev)
-            x0[lp.n:] = 0
-            y0[lp.m:] = 0
-            eng.set_iterate(x0[eng.cols[0]:eng.cols[1]], y0[eng.rows[0]:eng.rows[1]])
+            x0 = torch.randn(lp.n, generator=g).to(dev)          # original order; the engine's layout is the padded one
+            y0 = torch.randn(lp.m, generator=g).to(dev)
+            eng.set_iterate(eng.part.pad_cols(x0)[eng.cols[0]:eng.cols[1]], eng.part.pad_rows(y0)[eng.rows[0]:eng.rows[1]])
             eng.set_step(0.02, 1.1, 1.0, 0)
             eng.iterate(9, adaptive)
             eng.iterate(4, adaptive)
             x, y = eng.get_iterate(N.CUR)
             kkt = eng.kkt(N.CUR, 1.0)
-            res[adaptive] = (gather_solution(eng, x, lp.n).cpu(), eng.scalars()["eta"], kkt["kkt"], x0[:lp.n].cpu(), y0[:lp.m].cpu())
+            res[adaptive] = (gather_solution(eng, x, lp.n).cpu(), eng.scalars()["eta"], kkt["kkt"], x0.cpu(), y0.cpu())
         del eng
         if rank == 0:
             os.environ["PDLP_TILED"] = "0"
@@ -356,3 +363,58 @@ def test_two_ranks_split_products_match_single_rank():
         ret = man.dict()
         mp.spawn(_gpu_split_worker, args=(world, port, ret), nprocs=world, join=True)
         assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def _rccl_world1_worker(rank, world, port, ret):
+    """backend nccl (= RCCL) with the one rank this box has: the library's own communicator, its all-gather / all-reduce round
+    trip, and pdlp_iterate running the sharded sequence (collectives enqueued between the half-steps) -- bit for bit the
+    iterations of a handle without a communicator"""
+    import torchpdlp_amd as tp
+    from torchpdlp_amd import _native as N
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        # torch.distributed's RCCL first (what the engine's default path uses)
+        comm = tp.Comm()
+        assert comm.backend == "nccl" and comm.world == 1
+        full = torch.arange(12, dtype=torch.float32, device=dev)
+        comm.all_gather(full)
+        red = torch.ones(8, dtype=torch.float64, device=dev)
+        comm.all_reduce_sum(red)
+        assert torch.equal(full.cpu(), torch.arange(12, dtype=torch.float32)) and float(red.sum()) == 8.0
+        for dtype, kw in ((torch.float32, {}), (torch.float64, {}), (torch.float32, dict(vec_dtype=torch.float64))):
+            lp = gen_lp(40_000, 30_000, 6, seed=3, device=dev, recipe="mixed", dtype=torch.float64)
+            K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val.to(dtype))
+            vd = kw.get("vec_dtype", dtype)
+            mk = lambda: tp.PdlpEngine.from_full(K, lp.c.to(vd), lp.q.to(vd), lp.l.to(vd), lp.u.to(vd), lp.m_ineq, **kw)
+            e0, e1 = mk(), mk()
+            assert e1.enable_library_comm(dist=dist) and e1.lib_comm and not e0.lib_comm
+            g = torch.Generator().manual_seed(3)
+            x0 = torch.randn(lp.n, generator=g, dtype=torch.float64).to(dev, vd)
+            y0 = torch.randn(lp.m, generator=g, dtype=torch.float64).to(dev, vd)
+            for adaptive in (True, False):
+                outs = []
+                for e in (e0, e1):
+                    e.set_iterate(x0, y0)
+                    e.set_step(0.02, 1.1, 1.0, 0)
+                    e.iterate(9, adaptive)
+                    e.iterate(4, adaptive)
+                    x, y = e.get_iterate(N.CUR)
+                    outs.append((x.clone(), y.clone(), e.scalars()["eta"], e.kkt(N.CUR, 1.0)["kkt"]))
+                assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+                assert outs[0][2] == outs[1][2] and outs[0][3] == outs[1][3]
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_world1_library_communicator():
+    port = _free_port()
+    with mp.Manager() as man:
+        ret = man.dict()
+        mp.spawn(_rccl_world1_worker, args=(1, port, ret), nprocs=1, join=True)
+        assert dict(ret) == {0: "ok"}

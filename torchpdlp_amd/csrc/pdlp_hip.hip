@@ -14,6 +14,8 @@
 //     device memory, so a whole restart period runs without a host synchronisation.
 // This bandwidth-bound path uses no MFMA.  Written for gfx950 only.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library is resolved with dlopen when a communicator is asked for
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdint>
@@ -84,6 +86,51 @@ template <typename T> __device__ __forceinline__ T block_sum(T v, T* buf)
 #include "pdlp_kernel_tiled.inc"
 #include "pdlp_kernels_small.inc"
 #include "pdlp_kernel_mv.inc"
+
+// ------------------------------------------------------------------------------------------------
+// RCCL, resolved at run time (single-GPU use never touches it)
+// ------------------------------------------------------------------------------------------------
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    int last_error = 0;
+};
+Rccl g_rccl;
+
+int rccl_load(const char* path)
+{
+    if (g_rccl.lib) return PDLP_OK;
+    const char* names[] = {path, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* lib = nullptr;
+    for (const char* nm : names) {
+        if (!nm || !*nm) continue;
+        lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (lib) break;
+    }
+    if (!lib) return PDLP_ERR_COMM;
+    Rccl r;
+    r.lib = lib;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(lib, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))dlsym(lib, "ncclAllGather");
+    r.AllReduce = (decltype(r.AllReduce))dlsym(lib, "ncclAllReduce");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.AllReduce) return PDLP_ERR_COMM;
+    g_rccl = r;
+    return PDLP_OK;
+}
+
+#define RCCL_TRY(expr)                                       \
+    do {                                                     \
+        ncclResult_t r_ = (expr);                            \
+        if (r_ != ncclSuccess) { g_rccl.last_error = (int)r_; return PDLP_ERR_COMM; } \
+    } while (0)
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -170,6 +217,8 @@ struct pdlp_solver {
     // vector and is added to a float64 "anchor" product that is carried along: kxb[0] = K x_cur, ktyr = K'y (of y_cur once
     // dy_folded, else of the previous y with gdy = y_cur - y_prev still to be folded in by the next product with K')
     bool delta, anchors_valid, dy_folded;
+    ncclComm_t comm;              // RCCL communicator of a sharded problem (pdlp_comm_init), or null: the caller does the exchange
+    int comm_rank, comm_size;
     char* ktyr;                   // [nl] float64 running K'y
     float *gdx, *gdy;             // full-length float32 difference vectors the float32 kernels gather from
     int64_t nl, ml;               // local variable / constraint counts
@@ -216,6 +265,7 @@ void drop_graphs(pdlp_handle h)
 void free_handle(pdlp_handle h)
 {
     drop_graphs(h);
+    if (h->comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
     if (h->gstream) { (void)hipStreamSynchronize(h->gstream); (void)hipStreamDestroy(h->gstream); }
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->ev_out) (void)hipEventDestroy(h->ev_out);
@@ -869,7 +919,7 @@ int read_last_rowptr(const int32_t* rp, int64_t rows, int64_t* nnz, hipStream_t 
 // ================================================================================================
 extern "C" {
 
-int pdlp_abi_version(void) { return 6; }   // 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
+int pdlp_abi_version(void) { return 7; }   // 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
 
 const char* pdlp_strerror(int code)
 {
@@ -878,6 +928,9 @@ const char* pdlp_strerror(int code)
         case PDLP_ERR_INVALID: return "invalid argument";
         case PDLP_ERR_WORKSPACE: return "workspace too small or not 256-byte aligned";
         case PDLP_ERR_STATE: return "call sequence violated";
+        case PDLP_ERR_COMM:
+            return g_rccl.GetErrorString && g_rccl.last_error ? g_rccl.GetErrorString((ncclResult_t)g_rccl.last_error)
+                                                              : "RCCL could not be loaded or a collective failed";
         default: break;
     }
     if (code <= PDLP_ERR_HIP_BASE) return hipGetErrorString((hipError_t)(PDLP_ERR_HIP_BASE - code));
@@ -918,6 +971,7 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     h->stream = (hipStream_t)p->stream;
     h->es = p->dtype == PDLP_F32 ? 4 : 8;
     h->mixed = p->dtype == PDLP_MIXED;
+    h->comm = nullptr; h->comm_rank = 0; h->comm_size = 1;
     h->delta = false; h->anchors_valid = false; h->dy_folded = false;
     h->nl = nl;
     h->ml = ml;
@@ -1244,11 +1298,108 @@ pdlp_solver::IterGraph* pair_graph(pdlp_handle h, int adaptive)
 
 }  // namespace
 
+namespace {
+
+// all-gather of a full-length vector whose block of this rank is in place (equal blocks: rank r's block starts at r * count)
+int comm_all_gather(pdlp_handle h, void* full, int64_t count, bool f32)
+{
+    char* base = (char*)full;
+    const size_t esz = f32 ? 4 : 8;
+    RCCL_TRY(g_rccl.AllGather(base + (size_t)h->comm_rank * count * esz, base, (size_t)count, f32 ? ncclFloat32 : ncclFloat64, h->comm,
+                              h->stream));
+    return PDLP_OK;
+}
+
+// the iterations of a sharded problem with the exchange inside the library: the same sequence as PdlpEngine.iterate drives
+// through torch.distributed (engine.py), all of it enqueued on the handle's stream -- one call per restart period, no host
+// work between the kernels and the collectives
+int iterate_sharded(pdlp_handle h, int iters, int adaptive)
+{
+    int rc;
+    const bool vec32 = h->p.dtype == PDLP_F32;
+    if (h->delta && iters > 0 && !h->anchors_valid) {
+        if ((rc = comm_all_gather(h, h->xb[h->ix_cur], h->nl, vec32)) != PDLP_OK) return rc;
+        if ((rc = comm_all_gather(h, h->yb[h->ix_cur], h->ml, vec32)) != PDLP_OK) return rc;
+        if ((rc = delta_refresh(h)) != PDLP_OK) return rc;
+    }
+    for (int it = 0; it < iters; ++it) {
+        if ((rc = pdlp_primal_half(h, adaptive)) != PDLP_OK) return rc;
+        // the panels of K that meet this rank's own block of xbar are multiplied (side stream) while the other blocks are on the wire
+        if ((rc = pdlp_dual_half_begin(h, adaptive)) != PDLP_OK) return rc;
+        if (h->delta) rc = comm_all_gather(h, h->gdx, h->nl, true);
+        else rc = comm_all_gather(h, h->xbar, h->nl, vec32);
+        if (rc != PDLP_OK) return rc;
+        if ((rc = pdlp_dual_half(h, adaptive)) != PDLP_OK) return rc;
+        if (it + 1 < iters && (rc = pdlp_primal_half_begin(h)) != PDLP_OK) return rc;
+        if (h->delta) rc = comm_all_gather(h, h->gdy, h->ml, true);
+        else rc = comm_all_gather(h, h->yb[h->ix_cur], h->ml, vec32);
+        if (rc != PDLP_OK) return rc;
+        if (adaptive) {
+            if ((rc = pdlp_adaptive_reduce(h)) != PDLP_OK) return rc;
+            RCCL_TRY(g_rccl.AllReduce(h->red, h->red, 3, ncclFloat64, ncclSum, h->comm, h->stream));
+            if ((rc = pdlp_adaptive_update(h)) != PDLP_OK) return rc;
+        }
+    }
+    if (!adaptive && iters > 0) return pdlp_fixed_advance(h, iters);
+    return PDLP_OK;
+}
+
+}  // namespace
+
+int pdlp_comm_unique_id(const char* rccl_path, void* id128)
+{
+    if (!id128) return PDLP_ERR_INVALID;
+    const int rc = rccl_load(rccl_path);
+    if (rc != PDLP_OK) return rc;
+    ncclUniqueId id;
+    RCCL_TRY(g_rccl.GetUniqueId(&id));
+    std::memcpy(id128, &id, sizeof(id));
+    return PDLP_OK;
+}
+
+int pdlp_comm_init(pdlp_handle h, const char* rccl_path, const void* id128, int rank, int nranks)
+{
+    if (!h || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return PDLP_ERR_INVALID;
+    // equal blocks, this rank's at rank * block (the padded layout of torchpdlp_amd/distributed.py)
+    if (h->nl * nranks != h->p.n || h->ml * nranks != h->p.m || h->p.col0 != (int64_t)rank * h->nl || h->p.row0 != (int64_t)rank * h->ml)
+        return PDLP_ERR_INVALID;
+    const int rc = rccl_load(rccl_path);
+    if (rc != PDLP_OK) return rc;
+    if (h->comm) { (void)g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
+    HIP_TRY(hipSetDevice(h->p.device));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    RCCL_TRY(g_rccl.CommInitRank(&h->comm, nranks, id, rank));
+    h->comm_rank = rank; h->comm_size = nranks;
+    return PDLP_OK;
+}
+
+int pdlp_comm_all_gather(pdlp_handle h, int which)
+{
+    if (!h || !h->comm) return PDLP_ERR_STATE;
+    void* p = nullptr;
+    const int rc = pdlp_buffer_ptr(h, which, &p);
+    if (rc != PDLP_OK) return rc;
+    const bool is_x = which <= PDLP_BUF_X_AVG || which == PDLP_BUF_DX || which == PDLP_BUF_GDX;
+    if (which == PDLP_BUF_RED || which == PDLP_BUF_SCALARS || which == PDLP_BUF_X_SUM || which == PDLP_BUF_Y_SUM || which == PDLP_BUF_LAM_PREV)
+        return PDLP_ERR_INVALID;
+    const bool f32 = h->p.dtype == PDLP_F32 || which == PDLP_BUF_GDX || which == PDLP_BUF_GDY;
+    return comm_all_gather(h, p, is_x ? h->nl : h->ml, f32);
+}
+
+int pdlp_comm_all_reduce_red(pdlp_handle h)
+{
+    if (!h || !h->comm) return PDLP_ERR_STATE;
+    RCCL_TRY(g_rccl.AllReduce(h->red, h->red, PDLP_NRED, ncclFloat64, ncclSum, h->comm, h->stream));
+    return PDLP_OK;
+}
+
 int pdlp_iterate(pdlp_handle h, int iters, int adaptive)
 {
     if (!h || iters < 0) return PDLP_ERR_INVALID;
-    if (h->nl != h->p.n || h->ml != h->p.m) return PDLP_ERR_STATE;   // sharded problems need the caller's exchange
     adaptive = adaptive ? 1 : 0;
+    if (h->comm) return iterate_sharded(h, iters, adaptive);
+    if (h->nl != h->p.n || h->ml != h->p.m) return PDLP_ERR_STATE;   // sharded without a communicator: the caller does the exchange
     int rc, left = iters;
     if (h->graph_ok && left >= 5) {
         if (adaptive && !h->kx_valid) {          // the first adaptive iteration after a reset also refreshes the K x cache

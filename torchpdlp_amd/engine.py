@@ -122,6 +122,9 @@ class PdlpEngine:
         self.delta = False
         if self.mixed and (delta if delta is not None else os.environ.get("PDLP_DELTA", "1") != "0"):
             self.set_delta(True)
+        self.lib_comm = False
+        if self.comm is not None and self.comm.backend == "nccl" and os.environ.get("PDLP_LIB_COMM", "1") != "0":
+            self.enable_library_comm()
 
     # ---- panel-tiled matrix copies (fast path for wide gathered vectors) -------------------------------
     def tile_limits(self) -> dict:
@@ -196,6 +199,62 @@ class PdlpEngine:
         N.check(self.lib.pdlp_attach_tiles(self.h, int(transpose), C.byref(desc)), "pdlp_attach_tiles")
         self.tiles[int(transpose)] = t       # keep the arrays alive
         self.kernels[int(transpose)] = ("tiled" if t.groups == 1 else f"tiled/{t.groups} groups") + (f" + remainder {t.nrem}" if t.nrem else "")
+
+    # ---- the exchange inside the library (RCCL) --------------------------------------------------------------
+    @staticmethod
+    def _loaded_rccl():
+        """path of the RCCL library this process already has mapped (PyTorch's), so that the library joins the same one"""
+        try:
+            for line in open("/proc/self/maps"):
+                if "librccl" in line:
+                    return line.split()[-1]
+        except OSError:
+            pass
+        return None
+
+    def enable_library_comm(self, dist=None, group=None) -> bool:
+        """Give the handle its own RCCL communicator (``pdlp_comm_init``): ``iterate`` then is ONE library call per restart
+        period -- half-steps, all-gathers and the step-size all-reduce enqueued back to back on the stream -- instead of six
+        ctypes calls and three torch collectives per iteration.  The id travels over the existing process group; a round
+        trip of both collectives is checked against known values on every rank, and unless ALL ranks pass, all of them
+        stay on the torch.distributed path.  Returns whether the library path is on."""
+        if dist is None:
+            if self.comm is None:
+                return False
+            dist, group = self.comm.dist, self.comm.group
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        path = self._loaded_rccl()
+        cpath = None if path is None else path.encode()
+        idbuf = (C.c_char * 128)()
+        ok = 1
+        if rank == 0 and self.lib.pdlp_comm_unique_id(cpath, idbuf) != 0:
+            ok = 0
+        t = torch.tensor(list(idbuf.raw) + [ok], dtype=torch.uint8, device=self.device)
+        dist.broadcast(t, 0, group=group)
+        raw = bytes(t.cpu().tolist())
+        ok = raw[128]
+        C.memmove(idbuf, raw[:128], 128)
+        if ok and self.lib.pdlp_comm_init(self.h, cpath, idbuf, rank, world) != 0:
+            ok = 0
+        if ok:          # round trip: all-gather of a full-length float vector and the 8-double all-reduce
+            try:
+                dx, red = self.buffer(N.BUF_DX), self.buffer(N.BUF_RED)
+                dx.zero_()
+                dx[self.cols[0]:self.cols[1]] = rank + 1
+                red.fill_(rank + 1)
+                N.check(self.lib.pdlp_comm_all_gather(self.h, N.BUF_DX), "pdlp_comm_all_gather")
+                N.check(self.lib.pdlp_comm_all_reduce_red(self.h), "pdlp_comm_all_reduce_red")
+                self.stream.synchronize()
+                want = torch.arange(1, world + 1, device=self.device, dtype=dx.dtype).repeat_interleave(self.nl)
+                ok = int(torch.equal(dx, want) and bool((red == world * (world + 1) / 2).all()))
+                dx.zero_()
+                red.zero_()
+            except N.PdlpError:
+                ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        self.lib_comm = bool(int(flag))
+        return self.lib_comm
 
     def set_delta(self, on: bool):
         """delta mode of a mixed-precision engine (include/pdlp_hip.h, pdlp_set_delta)"""
@@ -286,7 +345,7 @@ class PdlpEngine:
     # ---- iterations ---------------------------------------------------------------------------------
     def iterate(self, iters: int, adaptive: bool):
         """`iters` PDHG iterations, no host synchronisation (pdhg.py:76-112)."""
-        if self.comm is None:
+        if self.comm is None or self.lib_comm:      # single GPU, or the exchange runs inside the library (RCCL)
             N.check(self.lib.pdlp_iterate(self.h, int(iters), int(adaptive)), "pdlp_iterate")
             return
         a = int(adaptive)
