@@ -218,12 +218,17 @@ int pdlp_refresh_products(pdlp_handle h);
 int pdlp_delta_state(pdlp_handle h, int32_t out[3]);
 
 /* ---- restart machinery ---------------------------------------------------------------------- */
-/* adds the not-yet-accumulated weight of the current iterate to the sums (adaptive mode defers
- * it by one step because the weight is only known after the step-size rule) */
-int pdlp_flush_average(pdlp_handle h);
+/* Closes the averaging period before a restart check.  adaptive != 0: adds the not-yet-accumulated weight of the current
+ * iterate to the sums (adaptive mode defers it by one step because the weight is only known after the step-size rule).
+ * Both modes: the handle also keeps running sums of w_k K x_k and w_k K'y_k (K is linear: they are K x_avg and K'y_avg up to
+ * the division), so that the check needs no product for the averaged iterate; K'y of the CURRENT y exists only once
+ * pdlp_kkt_local(PDLP_CUR) has run, so call that first -- otherwise this call falls back to products for the average. */
+int pdlp_flush_average(pdlp_handle h, int adaptive);
 /* x_avg = x_sum / eta_sum, y_avg = y_sum / eta_sum for this rank's block -- pdhg.py:118-119 */
 int pdlp_compute_average(pdlp_handle h);
-/* KKT pass at PDLP_CUR / PDLP_AVG / PDLP_PREV: two fused SpMV kernels accumulate
+/* KKT pass at PDLP_CUR / PDLP_AVG / PDLP_PREV: two fused kernels -- SpMVs, or vector passes where the product is already
+ * there (K x of the current iterate is carried along by the dual half-steps; K x_avg and K'y_avg come from the running sums
+ * after pdlp_flush_average + pdlp_compute_average: a check then costs ONE product, K'y_cur, instead of four) -- accumulate
  * {dual_res^2, l_dual'max(lam,0), u_dual'min(lam,0), c'x, primal_res^2, q'y} of this rank's block
  * into PDLP_BUF_RED[0..5] -- compute_residuals_and_duality_gap helpers.py:53-96 with
  * project_lambda_box helpers.py:3-39.  unscaled != 0 evaluates the un-preconditioned problem

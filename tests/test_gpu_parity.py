@@ -949,8 +949,10 @@ def test_full_size_10Mx10M_properties(monkeypatch):
 
 
 def test_kty_reuse_after_restart_checks_changes_nothing(monkeypatch, golden):
-    """the first primal half-step after a restart check takes K'y from the check's KKT pass (same kernel, same sums):
-    fixed-step solves are bit for bit those of the build that recomputes it, adaptive ones agree to rounding"""
+    """the first primal half-step after a restart check takes K'y from the check -- of the current iterate from its KKT pass (same
+    kernel, same sums), of an adopted average from the running sums (sum w_k K'y_k / sum w_k: equal to the product up to
+    rounding): fixed-step solves take the same restart decisions as the build that recomputes it and end within rounding of
+    it (bit for bit with PDLP_RUNNING_KKT=0), adaptive ones agree to the solver's tolerance"""
     g = golden("solve_trace.npz")
     for name, tiled in (("mixed_400x300", "0"), ("box_200x150", "0")):
         a, K, o, _ = golden_lp(g, name)
@@ -968,7 +970,9 @@ def test_kty_reuse_after_restart_checks_changes_nothing(monkeypatch, golden):
                                                             b0=dev(r["b0"]), trace=tr) + (tr,)
         x1, obj1, k1, n1, j1, st1, _, tr1 = outs[(False, True)]
         x0, obj0, k0, n0, j0, st0, _, tr0 = outs[(False, False)]
-        assert (k1, n1, j1, st1) == (k0, n0, j0, st0) and torch.equal(x1, x0) and tr1["kkt"] == tr0["kkt"]
+        assert (k1, n1, j1, st1) == (k0, n0, j0, st0)
+        close(x1, x0.cpu().numpy(), 2e-4)
+        np.testing.assert_allclose(tr1["kkt"], tr0["kkt"], rtol=2e-2)
         xa, obja, ka, na, ja, sta, _, _ = outs[(True, True)]
         xb, objb, kb, nb, jb, stb, _, _ = outs[(True, False)]
         assert sta == stb == "Solved" and abs(obja - objb) <= 2e-3 * (1 + abs(objb))
@@ -986,7 +990,7 @@ def test_kty_reuse_after_restart_checks_changes_nothing(monkeypatch, golden):
                                  precondition=True, primal_weight_update=True, adaptive_stepsize=False, seed=0)
     assert res[True].status == res[False].status == "Solved"
     assert (res[True].iterations, res[True].restarts, res[True].kkt_passes) == (res[False].iterations, res[False].restarts, res[False].kkt_passes)
-    assert torch.equal(res[True].x, res[False].x)
+    close(res[True].x, res[False].x.cpu().numpy(), 2e-4)
     # (fixed steps stop on the reference's SIGNED gap test, quirk Q2, well before the objective has settled)
     assert abs(res[True].objective - lp.opt_obj) <= 5e-2 * (1 + abs(lp.opt_obj))
 
@@ -1529,3 +1533,53 @@ def test_tiles_with_remainder_match_the_csr_kernel(monkeypatch, precision):
         np.testing.assert_allclose(b[2], a[2], rtol=1e-3 if precision == "f32" else 1e-5)
         for key in ("pr", "dr", "p", "d_adj", "kkt"):
             np.testing.assert_allclose(b[3][key], a[3][key], rtol=1e-3 if precision == "f32" else 1e-5)
+
+
+@pytest.mark.parametrize("tiled", ["0", "1"])
+def test_restart_check_from_running_products(monkeypatch, golden, tiled):
+    """K x is carried along by the dual half-steps and w_k K x_k, w_k K'y_k are summed with the average's weights, so a restart
+    check multiplies once (K'y of the current iterate) instead of four times.  Same KKT numbers as the all-products path
+    (PDLP_RUNNING_KKT=0) up to rounding, same iterates after a restart to the average, fixed and adaptive, over several periods"""
+    lp = gen_lp(60_000, 50_000, 8, seed=4, device=DEV, recipe="mixed")
+    K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
+    monkeypatch.setenv("PDLP_TILED", tiled)
+    engines = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("PDLP_RUNNING_KKT", flag)
+        engines[flag] = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    x0 = torch.minimum(torch.maximum(torch.randn(lp.n, device=DEV, generator=g), lp.l), lp.u)
+    y0 = torch.randn(lp.m, device=DEV, generator=g)
+    y0[:lp.m_ineq].clamp_(min=0)
+    for adaptive in (True, False):
+        res = {}
+        for flag, e in engines.items():
+            e.set_iterate(x0, y0)
+            e.set_step(0.01, 1.2, 1.0, 0)
+            out = []
+            for period in range(3):
+                e.iterate(40, adaptive)
+                r_cur = e.kkt(N.CUR, 1.2)
+                e.flush_average(adaptive)
+                e.compute_average()
+                r_avg = e.kkt(N.AVG, 1.2)
+                r_prev = e.kkt(N.PREV, 1.2)
+                out.append((r_cur, r_avg, r_prev))
+                if period == 1:
+                    e.restart(N.AVG)               # adopts K x_avg / K'y_avg (from the sums, or from the products)
+                    e.mark_restart_point()
+            e.iterate(7, adaptive)
+            x, y = e.get_iterate(N.CUR)
+            res[flag] = (out, x.cpu().numpy(), y.cpu().numpy(), e.scalars()["eta"])
+        for period, ((a_cur, a_avg, a_prev), (b_cur, b_avg, b_prev)) in enumerate(zip(res["1"][0], res["0"][0])):
+            # after the restart (period 2) the two runs continue from K x_avg / K'y_avg that differ in the last bits; the
+            # adaptive rule amplifies that (measured: 0.7 % in the residuals 40 steps later), the fixed step does not
+            rt = 5e-5 if (period < 2 or not adaptive) else 5e-2
+            for key in ("pr", "dr", "p", "d_adj", "kkt", "gap"):
+                scale = 1 + abs(b_avg["p"]) + abs(b_avg["d_adj"])
+                for a, b in ((a_cur, b_cur), (a_avg, b_avg), (a_prev, b_prev)):
+                    np.testing.assert_allclose(a[key], b[key], rtol=rt, atol=rt / 5 * scale, err_msg=f"{key} period {period}")
+        rt = 5e-2 if adaptive else 5e-5
+        close(res["1"][1], res["0"][1], rt)
+        close(res["1"][2], res["0"][2], rt)
+        np.testing.assert_allclose(res["1"][3], res["0"][3], rtol=5e-2 if adaptive else 1e-5)

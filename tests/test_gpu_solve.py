@@ -68,7 +68,8 @@ def test_cli_writes_the_reference_csv_schema(tmp_path):
     by = {r["File"]: r for r in rows}
     assert sorted(by) == ["afiro.mps", "all_eq.mps", "all_ineq.mps", "features.mps", "marker.mps"]
     assert by["afiro.mps"]["Status"] == "Solved" and abs(float(by["afiro.mps"]["Objective"]) - AFIRO_OPT) < 0.5
-    assert by["marker.mps"]["Status"].startswith("Solver failed: could not convert string to float")   # and the run went on
+    # a file that does not load: the reference's own row for it (main.py:92-103; short messages carry no prefix) -- and the run went on
+    assert by["marker.mps"]["Status"].startswith("could not convert string to float") and by["marker.mps"]["Objective"] == "N/A"
     assert by["all_eq.mps"]["Status"] == "Solved" and by["all_ineq.mps"]["Status"] == "Solved"
 
 

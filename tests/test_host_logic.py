@@ -49,7 +49,7 @@ class OracleEngine:
             self.ys += w * self.y
             self.es = self.t(self.es + w)
 
-    def flush_average(self):
+    def flush_average(self, adaptive=True):
         pass
 
     def compute_average(self):

@@ -10,7 +10,7 @@ csv.field_size_limit(1 << 30)
 
 
 def short(name):
-    m = re.search(r"(k_\w+)<(float|double)(?:, \(anonymous namespace\)::(\w+)<(?:float|double)(?:, (true|false))?>)?", name)
+    m = re.search(r"(k_\w+)<(float|double)(?:, (?:float|double))?(?:, \(anonymous namespace\)::(\w+)<(?:float|double|true|false)(?:, (true|false))?>)?", name)
     if not m:
         m2 = re.search(r"(k_\w+)", name)
         return m2.group(1) if m2 else None

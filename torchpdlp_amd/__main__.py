@@ -14,6 +14,7 @@ import sys
 import torch
 
 from .api import solve_lp
+from .mps import mps_to_standard_form
 
 COLUMNS = ["File", "Objective", "Iterations (k)", "Restarts (n)", "KKT Passes (j)", "Time (s)", "Status"]
 
@@ -70,11 +71,21 @@ def main(argv=None) -> int:
     for name in files:
         path = os.path.join(args.instance_path, name)
         print(f"\nProcessing {path}...")
+        dtype = torch.float32 if args.dtype == "fp32" else torch.float64
+        try:                            # main.py:88-103: a file that does not load gets its own kind of row
+            problem = mps_to_standard_form(path, device=torch.device("cuda", torch.cuda.current_device()), verbose=args.verbose,
+                                           compat=not args.standard_mps, dtype=dtype)
+        except Exception as e:
+            print(f"Failed to load MPS file: {path}. Error: {e}")
+            msg = str(e)
+            row = _fail_row(name, "Failed to load", e)
+            row["Status"] = f"Failed to load: {msg[:50]}..." if len(msg) > 50 else msg        # (the reference's quirk: main.py:101)
+            results.append(row)
+            continue
         try:
-            r = solve_lp(path, tol=args.tolerance, precondition=args.precondition, primal_weight_update=args.primal_weight_update,
+            r = solve_lp(problem, tol=args.tolerance, precondition=args.precondition, primal_weight_update=args.primal_weight_update,
                          adaptive_stepsize=args.adaptive_stepsize, max_kkt=args.max_kkt, time_limit=args.time_limit,
-                         verbose=args.verbose, dtype=torch.float32 if args.dtype == "fp32" else torch.float64, seed=args.seed,
-                         compat=not args.standard_mps, fishnet=args.fishnet, comm=comm,
+                         verbose=args.verbose, dtype=dtype, seed=args.seed, fishnet=args.fishnet, comm=comm,
                          infeasibility_detect=args.infeasibility_detect)
             print(f"Solver uses {r.time:.4f} seconds.\nStatus: {r.status}")
             results.append({"File": name, "Objective": f"{r.objective:.6f}", "Iterations (k)": r.iterations, "Restarts (n)": r.restarts,
@@ -82,6 +93,11 @@ def main(argv=None) -> int:
         except Exception as e:          # the reference records the failure and goes on (main.py:152-162)
             print(f"Solver failed for {name}. Error: {e}")
             results.append(_fail_row(name, "Solver failed", e))
+            if world > 1:
+                # a rank-local failure (out of memory on one shard, ...) leaves the other ranks inside a collective: do not go
+                # on to the next instance out of step -- leave, so that the job fails loudly instead of hanging
+                print(f"rank {rank}: leaving the sharded run after a failure in {name}", file=sys.stderr, flush=True)
+                os._exit(3)
     if rank != 0:
         return 0
     os.makedirs(args.output_path, exist_ok=True)

@@ -236,6 +236,16 @@ struct pdlp_solver {
     char* ktyb[2];                // K'y of the candidates, kept by their KKT passes: [0] current, [1] averaged iterate
     int kty_cur;                  // which of the two belongs to the CURRENT iterate after a restart (-1: see cand_valid[0])
     bool no_kty_reuse;            // PDLP_NO_KTY_REUSE: timing experiments
+    // running products: K x (kxb[0]) is carried along by every dual half-step and both products are summed with the
+    // average's weights (kx_sum, kty_sum), so a restart check evaluates K x_cur, K x_avg and K'y_avg WITHOUT products:
+    // one product (K'y_cur, kept for the next primal half-step) instead of four per check
+    char *kx_sum, *kty_sum;
+    int64_t since_reset;          // iterations since the sums were last zeroed (set_iterate / restart)
+    bool kty_tail_done;           // kty_sum already holds the term of the current y (added by the flush at a restart check)
+    bool sums_broken;             // a term was lost (flush before the K'y of the current iterate existed): no running average
+    bool avg_products;            // kxb[2] / ktyb[1] hold K x_avg / K'y_avg computed from the sums
+    bool cur_kx_cached;           // the KKT pass of the current iterate took K x from the cache (nothing to swap on restart)
+    bool no_running;              // PDLP_RUNNING_KKT=0: every KKT pass multiplies (round-1 behaviour)
     double *partA, *partB, *red, *sc;
     void* rowsum;                 // row sums of the tiled kernel on their way to the epilogue: [groups][rs_stride]
     int64_t rs_stride;            // rows + one row block
@@ -378,9 +388,12 @@ template <typename T> int primal_half_t(pdlp_handle h, int adaptive)
     // K'y of the current iterate may still be there from the restart check (of the current iterate if nothing moved
     // since, or of the candidate the restart adopted)
     const int src = (h->no_kty_reuse || h->graph_ok || h->sKT.pending) ? -1 : (h->kty_cur >= 0 ? h->kty_cur : (h->cand_valid[0] ? 0 : -1));
+    // K'y of the previous iterate's y joins the running sum unless this is the first half-step after a reset (that y is the
+    // restart point) or the restart check's flush has already added it
+    T* ksum = (h->since_reset > 0 && !h->kty_tail_done && !h->sums_broken && !h->no_running) ? (T*)h->kty_sum : nullptr;
     if (adaptive) {
         PrimalEpi<T, true> e{xloc<T>(h, h->ix_cur), xloc<T>(h, h->ix_prev), (T*)h->xbar + h->p.col0, (const T*)h->p.c,
-                             (const T*)h->p.l, (const T*)h->p.u, (T*)h->x_sum, sc};
+                             (const T*)h->p.l, (const T*)h->p.u, (T*)h->x_sum, sc, ksum};
         if (src >= 0) {
             h->last_gridA = h->nl > 0 ? grid_for(h->nl) : 0;
             return primal_from_kty<T>(h, src, e);
@@ -392,7 +405,7 @@ template <typename T> int primal_half_t(pdlp_handle h, int adaptive)
         return rc;
     }
     PrimalEpi<T, false> e{xloc<T>(h, h->ix_cur), xloc<T>(h, h->ix_prev), (T*)h->xbar + h->p.col0, (const T*)h->p.c,
-                          (const T*)h->p.l, (const T*)h->p.u, (T*)h->x_sum, sc};
+                          (const T*)h->p.l, (const T*)h->p.u, (T*)h->x_sum, sc, ksum};
     if (src >= 0) return primal_from_kty<T>(h, src, e);
     h->use_split = true;
     const int rc = launch_csr<T>(h, true, h->yb[h->ix_cur], e, h->partA);
@@ -411,22 +424,24 @@ template <typename T> int refresh_kx_t(pdlp_handle h)
 template <typename T> int dual_half_t(pdlp_handle h, int adaptive)
 {
     int rc;
+    if (!h->kx_valid && (rc = refresh_kx_t<T>(h)) != PDLP_OK) return rc;      // K x of the current x: carried along from here on
+    T* ksum = (h->sums_broken || h->no_running) ? nullptr : (T*)h->kx_sum;
     if (adaptive) {
-        if (!h->kx_valid && (rc = refresh_kx_t<T>(h)) != PDLP_OK) return rc;
         DualEpi<T, true> e{yloc<T>(h, h->ix_cur), yloc<T>(h, h->ix_prev), (const T*)h->p.q, (T*)h->y_sum, (T*)h->kxb[0],
-                           h->sc, h->ineq_end};
+                           h->sc, h->ineq_end, ksum};
         h->last_gridB = grid_of(h->sK, h->ml);
         h->use_split = true;
         rc = launch_csr<T>(h, false, h->xbar, e, h->partB);
     } else {
         DualEpi<T, false> e{yloc<T>(h, h->ix_cur), yloc<T>(h, h->ix_prev), (const T*)h->p.q, (T*)h->y_sum, (T*)h->kxb[0],
-                            h->sc, h->ineq_end};
+                            h->sc, h->ineq_end, ksum};
         h->use_split = true;
         rc = launch_csr<T>(h, false, h->xbar, e, h->partB);
-        h->kx_valid = false;
     }
     h->use_split = false; h->sK.pending = false;
     if (rc != PDLP_OK) return rc;
+    ++h->since_reset;
+    h->kty_tail_done = false; h->avg_products = false;
     const int t = h->ix_cur;   // the freshly written buffers become current, the old ones previous
     h->ix_cur = h->ix_prev;
     h->ix_prev = t;
@@ -435,31 +450,60 @@ template <typename T> int dual_half_t(pdlp_handle h, int adaptive)
     return PDLP_OK;
 }
 
-template <typename T> int kkt_local_t(pdlp_handle h, int which, int unscaled)
+// a fused epilogue over a vector of finished products (no matrix pass): KKT sums from running products, K'y kept by a check
+template <typename T, class Epi> int vector_pass(pdlp_handle h, int64_t rows, const void* products, Epi e, double* partials)
+{
+    if (rows == 0) return PDLP_OK;
+    hipLaunchKernelGGL((k_rowsum_epilogue<T, Epi>), dim3(grid_for(rows)), dim3(BLOCK), 0, h->stream, (const T*)products, 1, (int64_t)0,
+                       (int)rows, (const T*)nullptr, e, partials);
+    HIP_TRY(hipGetLastError());
+    return PDLP_OK;
+}
+
+template <typename T, bool UNSCALE> int kkt_local_u(pdlp_handle h, int which)
 {
     const int ix = which == PDLP_CUR ? h->ix_cur : (which == PDLP_AVG ? h->ix_avg : h->ix_prev);
-    T* kx_out = which == PDLP_CUR ? (T*)h->kxb[1] : (which == PDLP_AVG ? (T*)h->kxb[2] : nullptr);
-    // K'y of a candidate is the product the first primal half-step after the check needs again (same kernel, same
-    // sums): keep it.  (A pass at the current iterate after a restart to the average supersedes that restart's copy.)
-    T* kty_out = which == PDLP_CUR ? (T*)h->ktyb[0] : (which == PDLP_AVG ? (T*)h->ktyb[1] : nullptr);
-    if (which == PDLP_CUR || (which == PDLP_AVG && h->kty_cur == 1)) h->kty_cur = -1;     // (the copy about to be overwritten)
-    int rc;
-    if (unscaled) {
-        KktDualEpi<T, true> ed{xloc<T>(h, ix), (const T*)h->p.c, (const T*)h->p.l, (const T*)h->p.u, (const T*)h->p.d_col, kty_out};
-        if ((rc = launch_csr<T>(h, true, h->yb[ix], ed, h->partA)) != PDLP_OK) return rc;
-        KktPrimalEpi<T, true> ep{yloc<T>(h, ix), (const T*)h->p.q, (const T*)h->p.d_row, kx_out, h->ineq_end};
-        if ((rc = launch_csr<T>(h, false, h->xb[ix], ep, h->partB)) != PDLP_OK) return rc;
+    const T* dcol = UNSCALE ? (const T*)h->p.d_col : nullptr;
+    const T* drow = UNSCALE ? (const T*)h->p.d_row : nullptr;
+    int rc, gridA = grid_of(h->sKT, h->nl), gridB = grid_of(h->sK, h->ml);
+    if (which == PDLP_AVG && h->avg_products) {
+        // K'y_avg (ktyb[1]) and K x_avg (kxb[2]) were formed from the running sums by pdlp_compute_average: two vector passes
+        KktDualEpi<T, UNSCALE> ed{xloc<T>(h, ix), (const T*)h->p.c, (const T*)h->p.l, (const T*)h->p.u, dcol, nullptr};
+        if ((rc = vector_pass<T>(h, h->nl, h->ktyb[1], ed, h->partA)) != PDLP_OK) return rc;
+        KktPrimalEpi<T, UNSCALE> ep{yloc<T>(h, ix), (const T*)h->p.q, drow, nullptr, h->ineq_end};
+        if ((rc = vector_pass<T>(h, h->ml, h->kxb[2], ep, h->partB)) != PDLP_OK) return rc;
+        gridA = h->nl > 0 ? grid_for(h->nl) : 0;
+        gridB = h->ml > 0 ? grid_for(h->ml) : 0;
     } else {
-        KktDualEpi<T, false> ed{xloc<T>(h, ix), (const T*)h->p.c, (const T*)h->p.l, (const T*)h->p.u, nullptr, kty_out};
+        T* kx_out = which == PDLP_CUR ? (T*)h->kxb[1] : (which == PDLP_AVG ? (T*)h->kxb[2] : nullptr);
+        // K'y of a candidate is the product the first primal half-step after the check needs again (same kernel, same
+        // sums): keep it.  (A pass at the current iterate after a restart to the average supersedes that restart's copy.)
+        T* kty_out = which == PDLP_CUR ? (T*)h->ktyb[0] : (which == PDLP_AVG ? (T*)h->ktyb[1] : nullptr);
+        if (which == PDLP_CUR || (which == PDLP_AVG && h->kty_cur == 1)) h->kty_cur = -1;     // (the copy about to be overwritten)
+        KktDualEpi<T, UNSCALE> ed{xloc<T>(h, ix), (const T*)h->p.c, (const T*)h->p.l, (const T*)h->p.u, dcol, kty_out};
         if ((rc = launch_csr<T>(h, true, h->yb[ix], ed, h->partA)) != PDLP_OK) return rc;
-        KktPrimalEpi<T, false> ep{yloc<T>(h, ix), (const T*)h->p.q, nullptr, kx_out, h->ineq_end};
-        if ((rc = launch_csr<T>(h, false, h->xb[ix], ep, h->partB)) != PDLP_OK) return rc;
+        if (which == PDLP_CUR && h->kx_valid && !h->no_running) {
+            // K x of the current iterate is carried along by the dual half-steps (kxb[0]): no product
+            KktPrimalEpi<T, UNSCALE> ep{yloc<T>(h, ix), (const T*)h->p.q, drow, nullptr, h->ineq_end};
+            if ((rc = vector_pass<T>(h, h->ml, h->kxb[0], ep, h->partB)) != PDLP_OK) return rc;
+            gridB = h->ml > 0 ? grid_for(h->ml) : 0;
+            h->cur_kx_cached = true;
+        } else {
+            KktPrimalEpi<T, UNSCALE> ep{yloc<T>(h, ix), (const T*)h->p.q, drow, kx_out, h->ineq_end};
+            if ((rc = launch_csr<T>(h, false, h->xb[ix], ep, h->partB)) != PDLP_OK) return rc;
+            if (which == PDLP_CUR) h->cur_kx_cached = false;
+        }
     }
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partA, grid_of(h->sKT, h->nl), 4, h->red, 0);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partB, grid_of(h->sK, h->ml), 2, h->red, 4);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partA, gridA, 4, h->red, 0);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partB, gridB, 2, h->red, 4);
     HIP_TRY(hipGetLastError());
     if (which != PDLP_PREV) h->cand_valid[which == PDLP_CUR ? 0 : 1] = true;
     return PDLP_OK;
+}
+
+template <typename T> int kkt_local_t(pdlp_handle h, int which, int unscaled)
+{
+    return unscaled ? kkt_local_u<T, true>(h, which) : kkt_local_u<T, false>(h, which);
 }
 
 template <typename T> void kkt_finish_t(const double* r, double omega_d, double* out)
@@ -653,13 +697,30 @@ int delta_kkt_local(pdlp_handle h, int which)
 
 #define DISPATCH(h, fn, ...) ((h)->p.dtype == PDLP_F32 ? fn<float>(__VA_ARGS__) : fn<double>(__VA_ARGS__))
 
-template <typename T> int flush_t(pdlp_handle h)
+template <typename T> int flush_t(pdlp_handle h, int adaptive)
 {
-    hipLaunchKernelGGL(k_flush<T>, dim3(grid_for(h->nl)), dim3(BLOCK), 0, h->stream, h->nl, (T*)h->x_sum,
-                       (const T*)xloc<T>(h, h->ix_cur), h->sc);
-    hipLaunchKernelGGL(k_flush<T>, dim3(grid_for(h->ml)), dim3(BLOCK), 0, h->stream, h->ml, (T*)h->y_sum,
-                       (const T*)yloc<T>(h, h->ix_cur), h->sc);
-    hipLaunchKernelGGL(k_clear_pending, dim3(1), dim3(1), 0, h->stream, h->sc);
+    const bool running = !h->delta && !h->sums_broken && !h->no_running && h->since_reset > 0;
+    if (adaptive) {
+        // the weight of the current iterate became known only after its step-size rule: add it now
+        hipLaunchKernelGGL(k_flush<T>, dim3(grid_for(h->nl)), dim3(BLOCK), 0, h->stream, h->nl, (T*)h->x_sum,
+                           (const T*)xloc<T>(h, h->ix_cur), h->sc, (int)S_WPEND);
+        hipLaunchKernelGGL(k_flush<T>, dim3(grid_for(h->ml)), dim3(BLOCK), 0, h->stream, h->ml, (T*)h->y_sum,
+                           (const T*)yloc<T>(h, h->ix_cur), h->sc, (int)S_WPEND);
+        if (running && h->kx_valid)
+            hipLaunchKernelGGL(k_flush<T>, dim3(grid_for(h->ml)), dim3(BLOCK), 0, h->stream, h->ml, (T*)h->kx_sum, (const T*)h->kxb[0],
+                               h->sc, (int)S_WPEND);
+    }
+    // K'y of the current y exists only if the KKT pass of the current iterate ran before this call (it keeps it in ktyb[0])
+    if (running && !h->kty_tail_done) {
+        if (h->cand_valid[0] && h->kty_cur < 0) {
+            hipLaunchKernelGGL(k_flush<T>, dim3(grid_for(h->nl)), dim3(BLOCK), 0, h->stream, h->nl, (T*)h->kty_sum, (const T*)h->ktyb[0],
+                               h->sc, (int)(adaptive ? S_WPEND : S_ETA));
+            h->kty_tail_done = true;
+        } else if (adaptive) {
+            h->sums_broken = true;       // the pending weight is cleared below: that term of the sum is lost until the next restart
+        }
+    }
+    if (adaptive) hipLaunchKernelGGL(k_clear_pending, dim3(1), dim3(1), 0, h->stream, h->sc);
     HIP_TRY(hipGetLastError());
     return PDLP_OK;
 }
@@ -670,6 +731,14 @@ template <typename T> int average_t(pdlp_handle h)
                        (const T*)h->x_sum, h->sc);
     hipLaunchKernelGGL(k_average<T>, dim3(grid_for(h->ml)), dim3(BLOCK), 0, h->stream, h->ml, yloc<T>(h, h->ix_avg),
                        (const T*)h->y_sum, h->sc);
+    // the products of the average from the running sums (K is linear): K x_avg = sum w_k K x_k / sum w_k, the same for K'y
+    h->avg_products = false;
+    if (!h->delta && !h->sums_broken && !h->no_running && !h->graph_ok && h->since_reset > 0 && h->kty_tail_done && h->kx_valid) {
+        hipLaunchKernelGGL(k_average<T>, dim3(grid_for(h->ml)), dim3(BLOCK), 0, h->stream, h->ml, (T*)h->kxb[2], (const T*)h->kx_sum, h->sc);
+        hipLaunchKernelGGL(k_average<T>, dim3(grid_for(h->nl)), dim3(BLOCK), 0, h->stream, h->nl, (T*)h->ktyb[1], (const T*)h->kty_sum, h->sc);
+        if (h->kty_cur == 1) h->kty_cur = -1;
+        h->avg_products = true;
+    }
     HIP_TRY(hipGetLastError());
     return PDLP_OK;
 }
@@ -857,7 +926,7 @@ struct Carve {
 };
 
 // one layout function used by both the size query and pdlp_create
-int64_t layout(const pdlp_problem* p, int64_t nnzK, int64_t nnzKT, int64_t* offs /*[40]*/)
+int64_t layout(const pdlp_problem* p, int64_t nnzK, int64_t nnzKT, int64_t* offs /*[48]*/)
 {
     const int64_t es = p->dtype == PDLP_F32 ? 4 : 8;
     const int64_t nl = p->col1 - p->col0, ml = p->row1 - p->row0;
@@ -896,6 +965,8 @@ int64_t layout(const pdlp_problem* p, int64_t nnzK, int64_t nnzKT, int64_t* offs
     offs[k++] = c.take(mixed ? nl * es : 0);                      // 35    ktyr
     offs[k++] = c.take(mixed ? p->n * 4 : 0);                     // 36    gdx
     offs[k++] = c.take(mixed ? p->m * 4 : 0);                     // 37    gdy
+    offs[k++] = c.take(ml * es);                                  // 38    kx_sum  (running sum of w_k K x_k)
+    offs[k++] = c.take(nl * es);                                  // 39    kty_sum (running sum of w_k K'y_k)
     return c.off;
 }
 
@@ -919,7 +990,7 @@ int read_last_rowptr(const int32_t* rp, int64_t rows, int64_t* nnz, hipStream_t 
 // ================================================================================================
 extern "C" {
 
-int pdlp_abi_version(void) { return 7; }   // 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
+int pdlp_abi_version(void) { return 8; }   // 8: running products, pdlp_flush_average(h, adaptive); 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
 
 const char* pdlp_strerror(int code)
 {
@@ -942,7 +1013,7 @@ int pdlp_workspace_bytes(const pdlp_problem* p, int64_t* bytes)
     int rc = check_problem(p);
     if (rc != PDLP_OK || !bytes) return PDLP_ERR_INVALID;
     HIP_TRY(hipSetDevice(p->device));
-    int64_t nnzK = 0, nnzKT = 0, offs[40];
+    int64_t nnzK = 0, nnzKT = 0, offs[48];
     if ((rc = read_last_rowptr(p->K_rowptr, p->row1 - p->row0, &nnzK, (hipStream_t)p->stream)) != PDLP_OK) return rc;
     if ((rc = read_last_rowptr(p->KT_rowptr, p->col1 - p->col0, &nnzKT, (hipStream_t)p->stream)) != PDLP_OK) return rc;
     *bytes = layout(p, nnzK, nnzKT, offs);
@@ -961,7 +1032,7 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     if (nl > 0) HIP_TRY(hipMemcpyAsync(rpKT.data(), p->KT_rowptr, (size_t)(nl + 1) * 4, hipMemcpyDeviceToHost, pstream));
     HIP_TRY(hipStreamSynchronize(pstream));     // (ordered behind whatever produced the arrays on that stream)
     if (rpK[0] != 0 || rpKT[0] != 0) return PDLP_ERR_INVALID;
-    int64_t offs[40];
+    int64_t offs[48];
     const int64_t need = layout(p, rpK[ml], rpKT[nl], offs);
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255u)) return PDLP_ERR_WORKSPACE;
 
@@ -991,6 +1062,9 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     h->dxf = w + offs[29]; h->dyf = w + offs[30]; h->lam_prev = w + offs[31]; h->ktdy = w + offs[32];
     h->ktyb[0] = w + offs[33]; h->ktyb[1] = w + offs[34];
     h->ktyr = w + offs[35]; h->gdx = (float*)(w + offs[36]); h->gdy = (float*)(w + offs[37]);
+    h->kx_sum = w + offs[38]; h->kty_sum = w + offs[39];
+    h->since_reset = 0; h->kty_tail_done = false; h->avg_products = false; h->sums_broken = false; h->cur_kx_cached = false;
+    h->no_running = std::getenv("PDLP_RUNNING_KKT") != nullptr && std::getenv("PDLP_RUNNING_KKT")[0] == '0';
     h->kty_cur = -1;
     h->no_kty_reuse = std::getenv("PDLP_NO_KTY_REUSE") != nullptr;
     h->rs_stride = (nl > ml ? nl : ml) + (int64_t)TNT * TRPT_MAX_ANY;
@@ -1128,6 +1202,9 @@ int pdlp_set_iterate(pdlp_handle h, const void* x_local, const void* y_local)
     h->cand_valid[0] = h->cand_valid[1] = false;
     h->kty_cur = -1;
     h->anchors_valid = false; h->dy_folded = false;
+    HIP_TRY(hipMemsetAsync(h->kx_sum, 0, h->ml * h->es, h->stream));
+    HIP_TRY(hipMemsetAsync(h->kty_sum, 0, h->nl * h->es, h->stream));
+    h->since_reset = 0; h->kty_tail_done = false; h->avg_products = false; h->sums_broken = false; h->cur_kx_cached = false;
     return PDLP_OK;
 }
 
@@ -1194,7 +1271,7 @@ int pdlp_dual_half_begin(pdlp_handle h, int adaptive)
 {
     if (!h) return PDLP_ERR_INVALID;
     if (h->delta && !h->anchors_valid) return PDLP_OK;
-    if (!h->delta && adaptive && !h->kx_valid) return PDLP_OK;        // the K x refresh ahead of this half-step uses the same scratch
+    if (!h->delta && !h->kx_valid) return PDLP_OK;        // the K x refresh ahead of this half-step uses the same scratch
     return DISPATCH(h, half_begin_t, h, false, h->xbar);
 }
 
@@ -1271,6 +1348,8 @@ pdlp_solver::IterGraph* pair_graph(pdlp_handle h, int adaptive)
     // capture: the launch code runs unchanged against the library's stream; host-side roles are put back afterwards
     const int ix_cur = h->ix_cur, ix_prev = h->ix_prev, gA = h->last_gridA, gB = h->last_gridB;
     const bool kxv = h->kx_valid, c0 = h->cand_valid[0], c1 = h->cand_valid[1];
+    const int64_t sr = h->since_reset;
+    const bool ktd = h->kty_tail_done;
     hipStream_t user = h->stream;
     if (hipStreamBeginCapture(h->gstream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
@@ -1284,6 +1363,7 @@ pdlp_solver::IterGraph* pair_graph(pdlp_handle h, int adaptive)
     const hipError_t e = hipStreamEndCapture(h->gstream, &graph);
     h->ix_cur = ix_cur; h->ix_prev = ix_prev; h->last_gridA = gA; h->last_gridB = gB;
     h->kx_valid = kxv; h->cand_valid[0] = c0; h->cand_valid[1] = c1;
+    h->since_reset = sr; h->kty_tail_done = ktd;
     if (rc != PDLP_OK || e != hipSuccess || !graph ||
         hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0) != hipSuccess) {
         if (graph) (void)hipGraphDestroy(graph);
@@ -1436,10 +1516,10 @@ int pdlp_fixed_advance(pdlp_handle h, int iters)
     return PDLP_OK;
 }
 
-int pdlp_flush_average(pdlp_handle h)
+int pdlp_flush_average(pdlp_handle h, int adaptive)
 {
     if (!h) return PDLP_ERR_INVALID;
-    return DISPATCH(h, flush_t, h);
+    return DISPATCH(h, flush_t, h, adaptive ? 1 : 0);
 }
 
 int pdlp_compute_average(pdlp_handle h)
@@ -1501,10 +1581,12 @@ int pdlp_restart(pdlp_handle h, int which)
         HIP_TRY(hipGetLastError());
         return PDLP_OK;
     }
-    if (h->cand_valid[cand]) {     // K x and K'y of the chosen point were produced by its KKT pass
-        char* t = h->kxb[0];
-        h->kxb[0] = h->kxb[1 + cand];
-        h->kxb[1 + cand] = t;
+    if (h->cand_valid[cand]) {     // K x and K'y of the chosen point were produced by its KKT pass (or carried along)
+        if (!(cand == 0 && h->cur_kx_cached)) {
+            char* t = h->kxb[0];
+            h->kxb[0] = h->kxb[1 + cand];
+            h->kxb[1 + cand] = t;
+        }
         h->kx_valid = true;
         h->kty_cur = cand;
     } else {
@@ -1514,6 +1596,9 @@ int pdlp_restart(pdlp_handle h, int which)
     h->cand_valid[0] = h->cand_valid[1] = false;
     HIP_TRY(hipMemsetAsync(h->x_sum, 0, h->nl * h->es, h->stream));          // pdhg.py:58-60
     HIP_TRY(hipMemsetAsync(h->y_sum, 0, h->ml * h->es, h->stream));
+    HIP_TRY(hipMemsetAsync(h->kx_sum, 0, h->ml * h->es, h->stream));
+    HIP_TRY(hipMemsetAsync(h->kty_sum, 0, h->nl * h->es, h->stream));
+    h->since_reset = 0; h->kty_tail_done = false; h->avg_products = false; h->sums_broken = false; h->cur_kx_cached = false;
     hipLaunchKernelGGL(k_reset_average, dim3(1), dim3(1), 0, h->stream, h->sc);
     HIP_TRY(hipGetLastError());
     return PDLP_OK;

@@ -376,8 +376,9 @@ class PdlpEngine:
             N.check(self.lib.pdlp_fixed_advance(self.h, int(iters)), "pdlp_fixed_advance")
 
     # ---- restart machinery --------------------------------------------------------------------------
-    def flush_average(self):
-        N.check(self.lib.pdlp_flush_average(self.h), "pdlp_flush_average")
+    def flush_average(self, adaptive: bool = True):
+        """close the averaging period before a restart check (after ``kkt(CUR)``: include/pdlp_hip.h, pdlp_flush_average)"""
+        N.check(self.lib.pdlp_flush_average(self.h, int(bool(adaptive))), "pdlp_flush_average")
 
     def compute_average(self):
         N.check(self.lib.pdlp_compute_average(self.h), "pdlp_compute_average")

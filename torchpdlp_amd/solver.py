@@ -143,10 +143,11 @@ class PdhgDriver:
             eng.synchronize()
             t_check = time.perf_counter()
         self.checks += 1
-        if self.adaptive:
-            eng.flush_average()
-        eng.compute_average()                                               # pdhg.py:118-119
+        # the current iterate first: its pass keeps K'y, which closes the running sum of K'y_k -- the averaged iterate then
+        # needs no product at all (K x_avg and K'y_avg come out of the sums; include/pdlp_hip.h, pdlp_flush_average)
         r_cur = eng.kkt(N.CUR, self.omega)                                  # pdhg.py:122-125
+        eng.flush_average(self.adaptive)
+        eng.compute_average()                                               # pdhg.py:118-119
         r_avg = eng.kkt(N.AVG, self.omega)
         k_cur, k_avg = t(r_cur["kkt"]), t(r_avg["kkt"])
         k_min = min(k_cur, k_avg)
@@ -248,17 +249,23 @@ def run_pdlp(eng: PdlpEngine, max_kkt=100_000, tol=1e-4, verbose=True, restart_p
     while drv.j < max_kkt:                                                  # pdhg.py:54
         n_before = drv.n
         while drv.j < max_kkt and drv.n == n_before:                        # pdhg.py:67
-            expired = time.time() - t0 + time_used >= time_limit            # pdhg.py:68-74 (checked per block)
-            if eng.comm is not None:                                        # every rank must leave together: rank 0's clock decides
-                flag = torch.tensor([int(expired)], dtype=torch.int32, device=eng.device)
+            expired = time.time() - t0 + time_used >= time_limit            # pdhg.py:68-74
+            # the reference looks at the clock before every iteration; here at least every ~0.5 s of iterations: the budget
+            # per engine call shrinks when a single iteration is slow (measured on the run so far)
+            budget = max_kkt - drv.j
+            if drv.k >= 2 * drv.period:
+                per_iter = (time.time() - t0) / drv.k
+                budget = min(budget, max(1, int(0.5 / max(per_iter, 1e-9))))
+            if eng.comm is not None:                                        # every rank must take the same steps: rank 0 decides
+                flag = torch.tensor([int(expired), int(budget)], dtype=torch.int64, device=eng.device)
                 eng.comm.dist.broadcast(flag, 0, group=eng.comm.group)
-                expired = bool(int(flag.cpu()))
+                expired, budget = bool(int(flag[0])), int(flag[1])
             if expired:
                 status = STATUS_TIME_LIMIT
                 if verbose:
                     print("Time limit exceeded")
                 break
-            drv.advance(max_kkt - drv.j)
+            drv.advance(budget)
             if drv.infeasible:
                 break
         if drv.infeasible:                                                  # pdhg.py:94-100: leave at once with c'x
