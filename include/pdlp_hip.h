@@ -133,6 +133,16 @@ void pdlp_destroy(pdlp_handle h);
  * NULL goes back to the CSR arrays.  The arrays must outlive the handle and be 16-byte aligned.
  * Same results up to summation order; several times faster when the gathered vector exceeds the L2. */
 int pdlp_attach_tiles(pdlp_handle h, int transpose, const pdlp_tiles* t);
+/* The CSR kernel's row blocks (built by pdlp_create: <= 256 rows, <= 2048 non-zeros each): *blocks = device array of
+ * (first row, first non-zero) pairs, nblk + 1 of them.  For building the column-sorted copy below. */
+int pdlp_schedule_info(pdlp_handle h, int transpose, int32_t* nblk, const int32_t** blocks);
+/* Optional column-sorted copy of the items of K (transpose = 0) or K' (1) for the CSR kernel: inside every row block the items
+ * are sorted by column; sval = the values in that order (precision of the matrix), sidx = (slot << 21) | (column - cbase[block]),
+ * slot = the item's position in CSR order inside its block.  A wave's gathers then cover consecutive sorted items -- a few cache
+ * lines on banded / block-structured matrices (whose tiles would be nearly empty: torchpdlp_amd/tiled.py) instead of one per
+ * lane.  cbase[block] < 0: the block's columns span more than 2^21 and it is read in CSR order.  NULLs detach.  Same results up
+ * to nothing: the reduction order is the CSR one. */
+int pdlp_attach_sorted(pdlp_handle h, int transpose, const uint32_t* sidx, const void* sval, const int32_t* cbase);
 /* device address of one of the PDLP_BUF_* buffers (inside the workspace) */
 int pdlp_buffer_ptr(pdlp_handle h, int which, void** ptr);
 

@@ -1583,3 +1583,41 @@ def test_restart_check_from_running_products(monkeypatch, golden, tiled):
         close(res["1"][1], res["0"][1], rt)
         close(res["1"][2], res["0"][2], rt)
         np.testing.assert_allclose(res["1"][3], res["0"][3], rtol=5e-2 if adaptive else 1e-5)
+
+
+@pytest.mark.parametrize("precision", ["f32", "mixed"])
+def test_column_sorted_row_blocks_match_csr_order(monkeypatch, precision):
+    """banded matrix (every row's entries inside a band: nearly all items would leave the tiles, so it is not tiled): the CSR kernel
+    reads each row block's items sorted by column (pdlp_attach_sorted) -- products to the items' CSR slots, same reduction, so the
+    results are those of the plain CSR order bit for bit; plus a few rows longer than a block (chunked) and wide blocks (cbase < 0)"""
+    m = n = 300_000
+    k = 40
+    g = torch.Generator(device=DEV).manual_seed(6)
+    off = torch.randint(-1500, 1500, (m, k), device=DEV, generator=g)
+    cols = (torch.arange(m, device=DEV).view(-1, 1) + off) % n
+    cols[1000:1004] = torch.randint(0, n, (4, k), device=DEV, generator=g)            # four rows spread over all columns: wide blocks
+    cols = torch.sort(cols, dim=1)[0].reshape(-1).to(torch.int32)
+    rp = torch.arange(0, (m + 1) * k, k, dtype=torch.int64, device=DEV).to(torch.int32)
+    val = torch.rand(m * k, device=DEV, generator=g)
+    K = tp.CsrPair(m, n, rp, cols, val)
+    lp = gen_lp(n, m, 2, seed=1, device=DEV)                                          # (vectors of the right sizes)
+    vd = torch.float32 if precision == "f32" else torch.float64
+    kw = {} if precision == "f32" else dict(vec_dtype=torch.float64)
+    vec = [t.to(vd) for t in (lp.c, lp.q, lp.l, lp.u)]
+    monkeypatch.setenv("PDLP_SORTED", "0")
+    e0 = tp.PdlpEngine.from_full(K, *vec, lp.m_ineq, **kw)
+    monkeypatch.setenv("PDLP_SORTED", "auto")
+    e1 = tp.PdlpEngine.from_full(K, *vec, lp.m_ineq, **kw)
+    assert e0.kernels == ["csr", "csr"] and all(kk.startswith("csr, sorted row blocks") for kk in e1.kernels), e1.kernels
+    assert int((e1._sorted[0][2] < 0).sum()) >= 1                                    # the wide blocks stay in CSR order
+    x0 = torch.randn(n, device=DEV, generator=g).to(vd)
+    y0 = torch.randn(m, device=DEV, generator=g).to(vd)
+    assert torch.equal(e0.spmv(x0, False), e1.spmv(x0, False)) and torch.equal(e0.spmv(y0, True), e1.spmv(y0, True))
+    outs = []
+    for e in (e0, e1):
+        e.set_iterate(x0, y0)
+        e.set_step(0.01, 1.0, 1.0, 0)
+        e.iterate(6, True)
+        x, y = e.get_iterate(N.CUR)
+        outs.append((x, y, e.kkt(N.CUR, 1.0)["kkt"]))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PDLP_LIB", os.path.join(_HERE, "libpdlp_hip.so"))   # PDLP_LIB: profiling/ablation builds
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 PDLP_F32, PDLP_F64, PDLP_MIXED = 0, 1, 2
 CUR, AVG, PREV = 0, 1, 2
 (BUF_X_CUR, BUF_X_PREV, BUF_XBAR, BUF_X_AVG, BUF_Y_CUR, BUF_Y_PREV, BUF_Y_AVG, BUF_RED, BUF_X_SUM, BUF_Y_SUM,
@@ -50,6 +50,8 @@ SIGNATURES = {
     "pdlp_create": (_I, [C.POINTER(_H), C.POINTER(PdlpProblem), _P, _I64]),
     "pdlp_destroy": (None, [_H]),
     "pdlp_attach_tiles": (_I, [_H, _I, C.POINTER(PdlpTiles)]),
+    "pdlp_schedule_info": (_I, [_H, _I, C.POINTER(C.c_int32), C.POINTER(_P)]),
+    "pdlp_attach_sorted": (_I, [_H, _I, _P, _P, _P]),
     "pdlp_buffer_ptr": (_I, [_H, _I, C.POINTER(_P)]),
     "pdlp_set_iterate": (_I, [_H, _P, _P]),
     "pdlp_get_iterate": (_I, [_H, _I, _P, _P]),

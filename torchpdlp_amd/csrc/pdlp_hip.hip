@@ -145,6 +145,10 @@ struct Schedule {
     int32_t* lptr = nullptr;  // device, [nlong+1] their chunk ranges
     void* longpart = nullptr; // device, [nchunks] chunk sums
     int nchunks = 0, nlong = 0, lgrid = 0;
+    // column-sorted row blocks (optional, attached by the caller): the CSR kernel reads each block's items sorted by column
+    const uint32_t* sidx = nullptr;
+    const void* sval = nullptr;
+    const int32_t* cbase = nullptr;
     // panel-tiled copy (optional, attached by the caller): used instead of the CSR arrays when set
     bool tiled = false;
     pdlp_tiles t{};
@@ -343,8 +347,13 @@ int launch_mat(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* 
     const int32_t* rp = transpose ? h->p.KT_rowptr : h->p.K_rowptr;
     const int32_t* ci = transpose ? h->p.KT_colidx : h->p.K_colidx;
     const TV* va = (const TV*)(transpose ? h->p.KT_val : h->p.K_val);
-    hipLaunchKernelGGL((k_csr_fused<T, TV, Epi>), dim3(s.grid), dim3(BLOCK), 0, h->stream, s.blk, s.nblk, s.lch, s.nchunks,
-                       (T*)s.longpart, rp, ci, va, (const T*)vin, epi, partials);
+    if (s.sidx)
+        hipLaunchKernelGGL((k_csr_fused<T, TV, Epi, true>), dim3(s.grid), dim3(BLOCK), 0, h->stream, s.blk, s.nblk, s.lch, s.nchunks,
+                           (T*)s.longpart, rp, ci, va, s.sidx, (const TV*)s.sval, s.cbase, (const T*)vin, epi, partials);
+    else
+        hipLaunchKernelGGL((k_csr_fused<T, TV, Epi, false>), dim3(s.grid), dim3(BLOCK), 0, h->stream, s.blk, s.nblk, s.lch, s.nchunks,
+                           (T*)s.longpart, rp, ci, va, (const uint32_t*)nullptr, (const TV*)nullptr, (const int32_t*)nullptr,
+                           (const T*)vin, epi, partials);
     if (s.nlong > 0)
         hipLaunchKernelGGL((k_long_rows<T, Epi>), dim3(s.lgrid), dim3(BLOCK), 0, h->stream, s.lrow, s.lptr, s.nlong,
                            (const T*)s.longpart, epi, partials + (size_t)s.grid * NACC);
@@ -990,7 +999,7 @@ int read_last_rowptr(const int32_t* rp, int64_t rows, int64_t* nnz, hipStream_t 
 // ================================================================================================
 extern "C" {
 
-int pdlp_abi_version(void) { return 8; }   // 8: running products, pdlp_flush_average(h, adaptive); 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
+int pdlp_abi_version(void) { return 9; }   // 9: pdlp_attach_sorted; 8: running products, pdlp_flush_average(h, adaptive); 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
 
 const char* pdlp_strerror(int code)
 {
@@ -1184,6 +1193,25 @@ int pdlp_attach_tiles(pdlp_handle h, int transpose, const pdlp_tiles* t)
     s.t = *t;
     s.tiled = true;
     configure_split(h, transpose != 0);
+    return PDLP_OK;
+}
+
+int pdlp_schedule_info(pdlp_handle h, int transpose, int32_t* nblk, const int32_t** blocks)
+{
+    if (!h || !nblk || !blocks) return PDLP_ERR_INVALID;
+    const Schedule& s = transpose ? h->sKT : h->sK;
+    *nblk = s.nblk;
+    *blocks = s.blk;
+    return PDLP_OK;
+}
+
+int pdlp_attach_sorted(pdlp_handle h, int transpose, const uint32_t* sidx, const void* sval, const int32_t* cbase)
+{
+    if (!h) return PDLP_ERR_INVALID;
+    if ((sidx == nullptr) != (sval == nullptr) || (sidx == nullptr) != (cbase == nullptr)) return PDLP_ERR_INVALID;
+    Schedule& s = transpose ? h->sKT : h->sK;
+    drop_graphs(h);
+    s.sidx = sidx; s.sval = sval; s.cbase = cbase;
     return PDLP_OK;
 }
 

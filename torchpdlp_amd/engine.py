@@ -115,6 +115,7 @@ class PdlpEngine:
         N.check(self.lib.pdlp_create(C.byref(self.h), C.byref(self.prob), self.workspace.data_ptr() + self._ws_off,
                                      nbytes.value), "pdlp_create")
         self._views = {}
+        self._sorted = [None, None]
         self._mv_work = {}
         self.tiles = [None, None]
         self.kernels = ["csr", "csr"]
@@ -143,6 +144,9 @@ class PdlpEngine:
         (not reproducible run to run; tuning only).  ``self.kernels`` records the choice per matrix."""
         mode = os.environ.get("PDLP_TILED", "auto")
         self.kernels = ["csr", "csr"]
+        if os.environ.get("PDLP_SORTED") == "1":            # tests / tuning: sorted row blocks for every matrix the CSR kernel keeps
+            for transpose in (0, 1):
+                self.attach_sorted(transpose)
         if mode == "0":
             return
         lim = self.tile_limits()
@@ -156,6 +160,9 @@ class PdlpEngine:
             t = _tiled.build_tiles(rp, ci, va, rows, cols, lw=knob("PDLP_TILE_LW"), rpt=knob("PDLP_TILE_RPT"),
                                    groups=knob("PDLP_TILE_GROUPS"), max_groups=lim["max_groups"])
             if t is None or t.nblk > lim["max_blocks"]:
+                # clustered (banded, block structured): the CSR kernel, with every row block's items sorted by column
+                if t is None and os.environ.get("PDLP_SORTED", "auto") != "0":
+                    self.attach_sorted(transpose)
                 continue
             if mode != "time":
                 self.attach_tiles(transpose, t)
@@ -178,6 +185,42 @@ class PdlpEngine:
         b.record(self.stream)
         b.synchronize()
         return a.elapsed_time(b) / reps
+
+    def attach_sorted(self, transpose: int, on: bool = True):
+        """Column-sorted copy of every row block's items for the CSR kernel (``pdlp_attach_sorted``): for matrices whose entries
+        cluster (banded, block structured) a wave's gathers then touch a few cache lines instead of one per lane.  Same sums."""
+        transpose = int(transpose)
+        if not on:
+            N.check(self.lib.pdlp_attach_sorted(self.h, transpose, None, None, None), "pdlp_attach_sorted")
+            self._sorted[transpose] = None
+            self.kernels[transpose] = "csr"
+            return
+        rp, ci, va = self.KT if transpose else self.K
+        nnz = int(va.numel())
+        if nnz == 0:
+            return
+        nb, bp = C.c_int32(0), C.c_void_p()
+        N.check(self.lib.pdlp_schedule_info(self.h, transpose, C.byref(nb), C.byref(bp)), "pdlp_schedule_info")
+        off = bp.value - self.workspace.data_ptr()
+        blk = self.workspace[off:off + (nb.value + 1) * 8].view(torch.int32).view(-1, 2)
+        first = blk[:, 1].long()                                   # first non-zero of every block (and the end)
+        lens = first[1:] - first[:-1]
+        dev = self.device
+        bid = torch.repeat_interleave(torch.arange(nb.value, device=dev), lens)
+        cl = ci.long()
+        big = torch.iinfo(torch.int64).max
+        cmin = torch.full((nb.value,), big, dtype=torch.int64, device=dev).scatter_reduce_(0, bid, cl, "amin")
+        cmax = torch.full((nb.value,), -1, dtype=torch.int64, device=dev).scatter_reduce_(0, bid, cl, "amax")
+        ok = (lens > 0) & (lens <= 2048) & (cmax - cmin < (1 << 21))
+        order = torch.argsort((bid << 32) | cl, stable=True)        # by (block, column); blocks stay in place
+        slot = (torch.arange(nnz, device=dev) - first[bid])[order]
+        sidx = (slot << 21) | (cl[order] - cmin[bid]).clamp_(0, (1 << 21) - 1)
+        sidx = torch.where(sidx >= 2 ** 31, sidx - 2 ** 32, sidx).to(torch.int32)
+        sval = va[order].contiguous()
+        cbase = torch.where(ok, cmin, torch.full_like(cmin, -1)).to(torch.int32)
+        N.check(self.lib.pdlp_attach_sorted(self.h, transpose, sidx.data_ptr(), sval.data_ptr(), cbase.data_ptr()), "pdlp_attach_sorted")
+        self._sorted[transpose] = (sidx, sval, cbase)              # keep the arrays alive
+        self.kernels[transpose] = f"csr, sorted row blocks ({int(ok.sum())} of {nb.value})"
 
     def attach_tiles(self, transpose: int, t: Optional["_tiled.Tiles"]):
         if t is None:

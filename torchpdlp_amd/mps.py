@@ -98,29 +98,37 @@ def parse_mps(mps_file: str, compat: bool = True):
                     lo[name], up[name] = 0.0, 1.0
     n = len(var_names)
     # every entry must name a declared row (the reference raises KeyError at util.py:183)
-    for r in ent_row:
-        if r not in row_sense:
-            raise KeyError(r)
-    # last occurrence of a (row, column) pair wins (dense assignment, util.py:183)
-    ent = {}
-    for j, r, v in zip(ent_var, ent_row, ent_val):
-        ent[(r, j)] = v
+    row_id = {name: i for i, name in enumerate(row_order)}
+    try:
+        R = np.fromiter((row_id[r] for r in ent_row), dtype=np.int64, count=len(ent_row))
+    except KeyError as e:
+        raise KeyError(e.args[0])
+    J = np.asarray(ent_var, dtype=np.int64)
+    V = np.asarray(ent_val, dtype=np.float64)
+    del ent_row, ent_var, ent_val
+    # last occurrence of a (row, column) pair wins (dense assignment, util.py:183); vectorised (round 2: the per-entry
+    # dictionaries of round 1 made files beyond ~1e7 non-zeros unusable): stable sort by (row, column), keep each group's last
+    order = np.argsort(R * max(n, 1) + J, kind="stable")
+    ks = (R * max(n, 1) + J)[order]
+    keep = np.ones(ks.size, dtype=bool)
+    keep[:-1] = ks[1:] != ks[:-1]
+    sel = order[keep]
+    R, J, V = R[sel], J[sel], V[sel]                  # now sorted by (row, column)
     c = np.zeros(n)
-    by_row = {}
-    for (r, j), v in ent.items():
-        if r == obj_row:
-            c[j] = v                                  # util.py:172-177
-        else:
-            by_row.setdefault(r, []).append((j, v))
+    if obj_row is not None:                           # util.py:172-177
+        mo = R == row_id[obj_row]
+        c[J[mo]] = V[mo]
+    starts = np.zeros(len(row_order) + 1, np.int64)
+    starts[1:] = np.cumsum(np.bincount(R, minlength=len(row_order)))
     # constraint rows in ROWS order: inequality block then equality block (util.py:190-231,250-261)
-    g_rows, g_rhs, a_rows, a_rhs = [], [], [], []
+    g_src, g_sign, g_rhs, a_src, a_rhs = [], [], [], [], []
     for name in row_order:
         if name == obj_row:
             continue
         sense = row_sense[name]
         b = rhs.get(name, 0.0)
         rng = ranges.get(name)
-        cols = by_row.get(name, [])
+        src = row_id[name]
         if rng is not None:                           # util.py:197-217
             if sense == "G":
                 lb, ub = b, b + abs(rng)
@@ -130,34 +138,35 @@ def parse_mps(mps_file: str, compat: bool = True):
                 lb, ub = (b, b + rng) if rng > 0 else (b + rng, b)
             else:
                 raise ValueError(f"Unsupported ranged sense: {sense}")
-            g_rows.append((cols, 1.0))
-            g_rhs.append(lb)
-            g_rows.append((cols, -1.0))
-            g_rhs.append(-ub)
+            g_src += [src, src]
+            g_sign += [1.0, -1.0]
+            g_rhs += [lb, -ub]
         elif sense == "E":                            # util.py:220-222
-            a_rows.append((cols, 1.0))
+            a_src.append(src)
             a_rhs.append(b)
         elif sense == "G":                            # util.py:223-225
-            g_rows.append((cols, 1.0))
+            g_src.append(src)
+            g_sign.append(1.0)
             g_rhs.append(b)
         elif sense == "L":                            # util.py:226-228
-            g_rows.append((cols, -1.0))
+            g_src.append(src)
+            g_sign.append(-1.0)
             g_rhs.append(-b)
-    rows = g_rows + a_rows
-    m_ineq, m = len(g_rows), len(rows)
+    m_ineq, m = len(g_src), len(g_src) + len(a_src)
     if m == 0:
         raise RuntimeError("the model has no constraint rows (the reference fails in torch.vstack, util.py:260)")
+    src = np.asarray(g_src + a_src, dtype=np.int64)
+    sign = np.asarray(g_sign + [1.0] * len(a_src), dtype=np.float64)
+    lens = starts[src + 1] - starts[src]
     rowptr = np.zeros(m + 1, np.int64)
-    colidx, vals = [], []
-    for i, (cols, sign) in enumerate(rows):
-        cols = sorted(cols)
-        colidx.extend(j for j, _ in cols)
-        vals.extend(sign * v for _, v in cols)
-        rowptr[i + 1] = len(colidx)
+    rowptr[1:] = np.cumsum(lens)
+    pos = np.repeat(starts[src] - rowptr[:-1], lens) + np.arange(int(rowptr[-1]))     # source position of every output entry
+    colidx = J[pos]
+    vals = np.repeat(sign, lens) * V[pos]
     q = np.array(g_rhs + a_rhs, dtype=np.float64)
     l = np.array([lo.get(v, 0.0) if lo.get(v, 0.0) is not None else 0.0 for v in var_names], dtype=np.float64)   # util.py:234-239
     u = np.array([up.get(v, np.inf) if up.get(v, np.inf) is not None else np.inf for v in var_names], dtype=np.float64)
-    return c, (rowptr, np.asarray(colidx, np.int64), np.asarray(vals, np.float64), m, n), q, m_ineq, l, u
+    return c, (rowptr, colidx.astype(np.int64), vals.astype(np.float64), m, n), q, m_ineq, l, u
 
 
 def mps_to_standard_form(mps_file, device="cpu", support_sparse=True, verbose=False, *, compat: bool = True,
