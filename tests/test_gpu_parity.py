@@ -1590,11 +1590,11 @@ def test_column_sorted_row_blocks_match_csr_order(monkeypatch, precision):
     """banded matrix (every row's entries inside a band: nearly all items would leave the tiles, so it is not tiled): the CSR kernel
     reads each row block's items sorted by column (pdlp_attach_sorted) -- products to the items' CSR slots, same reduction, so the
     results are those of the plain CSR order bit for bit; plus a few rows longer than a block (chunked) and wide blocks (cbase < 0)"""
-    m = n = 300_000
+    m, n = 300_000, 3_000_000               # wider than the 2^21 columns a sorted block's offsets can span
     k = 40
     g = torch.Generator(device=DEV).manual_seed(6)
     off = torch.randint(-1500, 1500, (m, k), device=DEV, generator=g)
-    cols = (torch.arange(m, device=DEV).view(-1, 1) + off) % n
+    cols = (10 * torch.arange(m, device=DEV).view(-1, 1) + off) % n
     cols[1000:1004] = torch.randint(0, n, (4, k), device=DEV, generator=g)            # four rows spread over all columns: wide blocks
     cols = torch.sort(cols, dim=1)[0].reshape(-1).to(torch.int32)
     rp = torch.arange(0, (m + 1) * k, k, dtype=torch.int64, device=DEV).to(torch.int32)
@@ -1606,7 +1606,7 @@ def test_column_sorted_row_blocks_match_csr_order(monkeypatch, precision):
     vec = [t.to(vd) for t in (lp.c, lp.q, lp.l, lp.u)]
     monkeypatch.setenv("PDLP_SORTED", "0")
     e0 = tp.PdlpEngine.from_full(K, *vec, lp.m_ineq, **kw)
-    monkeypatch.setenv("PDLP_SORTED", "auto")
+    monkeypatch.setenv("PDLP_SORTED", "1")         # ("auto" sorts only matrices that were candidates for tiles: K here, not the thin K')
     e1 = tp.PdlpEngine.from_full(K, *vec, lp.m_ineq, **kw)
     assert e0.kernels == ["csr", "csr"] and all(kk.startswith("csr, sorted row blocks") for kk in e1.kernels), e1.kernels
     assert int((e1._sorted[0][2] < 0).sum()) >= 1                                    # the wide blocks stay in CSR order
