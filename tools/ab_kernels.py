@@ -38,12 +38,17 @@ def measure(eng, adaptive=1):
 
 
 engines = []
-for path in libs:
+for spec in libs:                      # "lib.so" or "lib.so:ENV=VALUE" (the variable is set while that engine is built)
+    path, _, env = spec.partition(":")
+    if env:
+        os.environ[env.split("=")[0]] = env.split("=")[1]
     load(path)
     eng = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
     eng.set_step(0.01, 1.0, 1.0, 0)
     eng.iterate(2, True)
-    engines.append((path, eng))
+    engines.append((spec, eng))
+    if env:
+        os.environ.pop(env.split("=")[0], None)
 for rnd in range(rounds):
     for path, eng in engines:
         pm, dm, pa, da = measure(eng)
