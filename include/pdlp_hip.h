@@ -224,6 +224,12 @@ int pdlp_comm_all_reduce_red(pdlp_handle h);
  * and y), and x, y of the current iterate before pdlp_refresh_products. */
 int pdlp_set_delta(pdlp_handle h, int on);
 int pdlp_refresh_products(pdlp_handle h);
+/* The anchors from outside: kx_local = K x (this rank's constraints), kty_local = K'y (this rank's variables) of the CURRENT iterate,
+ * float64 device arrays.  For matrices that are not float32-valued (any float64 K, a Ruiz-scaled K): the handle then holds K
+ * ROUNDED to float32 -- the products of the iterations only ever see difference vectors, where the rounding of K costs what the
+ * float32 products cost anyway, 6e-8 ||K|| ||dx|| -- and the caller evaluates the anchors with the true float64 matrix (a second,
+ * float64 handle) after every restart instead of calling pdlp_refresh_products. */
+int pdlp_set_anchors(pdlp_handle h, const void* kx_local, const void* kty_local);
 /* out = {delta mode on, anchors valid, the pending dy is folded into K'y} */
 int pdlp_delta_state(pdlp_handle h, int32_t out[3]);
 

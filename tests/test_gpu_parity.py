@@ -1442,9 +1442,18 @@ def test_mixed_precision_solves_below_float32_resolution(golden):
             res[(tag, adaptive)] = (obj, k)
     assert abs(res[("mixed", True)][0] - res[("f64", True)][0]) <= 1e-8 * (1 + abs(opt))
     assert 0.3 * res[("f64", True)][1] <= res[("mixed", True)][1] <= 3 * res[("f64", True)][1]      # same algorithm, same pace
-    with pytest.raises(ValueError):
-        tp.pdlp_algorithm(tp.CsrPair(K64.m, K64.n, K64.rowptr, K64.colidx, K64.val * (1 + 1e-9)), int(a["m_ineq"]), *vecs, DEV,
-                          precision="mixed", verbose=False)
+    # a matrix that is NOT float32-valued: the iterations run on its float32 rounding, the anchors and the termination test on
+    # the true float64 matrix (pdlp_set_anchors) -- same answer as the float64 engine on that matrix
+    Kp = tp.CsrPair(K64.m, K64.n, K64.rowptr, K64.colidx, K64.val * (1 + 3e-9 * torch.arange(K64.nnz, device=DEV) % 7))
+    assert not bool((Kp.val.float().double() == Kp.val).all())
+    outs = {}
+    for kw in (dict(), dict(precision="mixed")):
+        x, obj, k, n, j, status, _ = tp.pdlp_algorithm(Kp, int(a["m_ineq"]), *vecs, DEV, tol=1e-9, verbose=False, adaptive=True,
+                                                       primal_update=True, seed=3, max_kkt=600_000, **kw)
+        assert status == "Solved", (kw, status, k)
+        outs[bool(kw)] = (obj, k)
+    assert abs(outs[True][0] - outs[False][0]) <= 1e-8 * (1 + abs(outs[False][0]))
+    assert 0.3 * outs[False][1] <= outs[True][1] <= 3 * outs[False][1]
 
 
 # ---------------------------------------------------------------------------------------------------

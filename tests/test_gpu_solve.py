@@ -58,6 +58,22 @@ def test_float64_reaches_a_tolerance_below_float32_resolution():
     assert res.status == "Solved" and abs(res.objective - AFIRO_OPT) <= 2e-8 * (1 + 2 * abs(AFIRO_OPT))   # gap test: 1e-8 (1+|p|+|d|)
 
 
+def test_mixed_precision_with_ruiz_reaches_1e_8_on_afiro():
+    """BASELINE configs[4]'s combination at a tolerance float32 cannot certify: Ruiz + adaptive step + primal weight, mixed precision.
+    The Ruiz-scaled matrix is not float32-valued: delta mode iterates on its float32 rounding and evaluates the anchors and the
+    (un-scaled) termination test with the true float64 matrix."""
+    c, K, q, m_ineq, l, u = tp.mps_to_standard_form(os.path.join(MPS_DIR, "afiro.mps"), device="cuda:0", dtype=torch.float64)
+    Ks, cs, qs, ls, us, dp, _ = tp.ruiz_precondition(c, K, q, l, u, device="cuda:0")
+    res = {}
+    for kw in (dict(), dict(precision="mixed")):
+        x, obj, k, n, j, status, _ = tp.pdlp_algorithm(Ks, m_ineq, cs, qs, ls, us, "cuda:0", tol=1e-8, verbose=False, precondition=True,
+                                                       primal_update=True, adaptive=True, data_precond=dp, seed=3, max_kkt=2_000_000, **kw)
+        assert status == "Solved", (kw, status)
+        assert abs(obj - AFIRO_OPT) <= 2e-8 * (1 + 2 * abs(AFIRO_OPT))
+        res[bool(kw)] = (obj, k)
+    assert 0.3 * res[False][1] <= res[True][1] <= 3 * res[False][1]
+
+
 def test_cli_writes_the_reference_csv_schema(tmp_path):
     from torchpdlp_amd.__main__ import COLUMNS, main
     rc = main(["--instance_path", MPS_DIR, "--output_path", str(tmp_path), "--adaptive_stepsize", "--primal_weight_update",

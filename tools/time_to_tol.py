@@ -32,8 +32,8 @@ def _heartbeat():           # long restart periods print nothing for minutes; th
 t0 = time.time()
 _heartbeat()
 lp = tp.gen_lp(n, n, k, seed=0, device=dev, dtype=dt)
-K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val.float() if prec == "mixed" else lp.val)
-if prec == "mixed":
+K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val.float() if (prec == "mixed" and not ruiz) else lp.val)
+if prec == "mixed" and not ruiz:
     assert bool((K.val.double() == lp.val).all())
     lp.val = None
 c, q, l, u = lp.c, lp.q, lp.l, lp.u
@@ -42,7 +42,11 @@ t_ruiz = 0.0
 if ruiz:
     K, c, q, l, u, dp, t_ruiz = tp.ruiz_precondition(c, K, q, l, u, device=dev)
     dcol, drow = dp[0], dp[1]
-eng = tp.PdlpEngine.from_full(K, c, q, l, u, lp.m_ineq, d_col=dcol, d_row=drow, vec_dtype=torch.float64 if prec == "mixed" else None)
+if prec == "mixed" and ruiz:      # the scaled matrix is not float32-valued: iterate on its rounding, anchors from the float64 one
+    Kh = K.to(dtype=torch.float32)
+    eng = tp.PdlpEngine.from_full(Kh, c, q, l, u, lp.m_ineq, d_col=dcol, d_row=drow, vec_dtype=torch.float64, exact=K)
+else:
+    eng = tp.PdlpEngine.from_full(K, c, q, l, u, lp.m_ineq, d_col=dcol, d_row=drow, vec_dtype=torch.float64 if prec == "mixed" else None)
 torch.cuda.synchronize()
 print(f"setup {time.time()-t0:.1f}s (ruiz {t_ruiz:.2f}s) kernels={eng.kernels} precision={prec} delta={eng.delta}", flush=True)
 trace = dict(kkt=[], omega=[], restarts=[])

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PDLP_LIB", os.path.join(_HERE, "libpdlp_hip.so"))   # PDLP_LIB: profiling/ablation builds
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 PDLP_F32, PDLP_F64, PDLP_MIXED = 0, 1, 2
 CUR, AVG, PREV = 0, 1, 2
 (BUF_X_CUR, BUF_X_PREV, BUF_XBAR, BUF_X_AVG, BUF_Y_CUR, BUF_Y_PREV, BUF_Y_AVG, BUF_RED, BUF_X_SUM, BUF_Y_SUM,
@@ -73,6 +73,7 @@ SIGNATURES = {
     "pdlp_comm_all_reduce_red": (_I, [_H]),
     "pdlp_set_delta": (_I, [_H, _I]),
     "pdlp_refresh_products": (_I, [_H]),
+    "pdlp_set_anchors": (_I, [_H, _P, _P]),
     "pdlp_delta_state": (_I, [_H, C.POINTER(C.c_int32)]),
     "pdlp_fixed_advance": (_I, [_H, _I]),
     "pdlp_flush_average": (_I, [_H, _I]),

@@ -654,30 +654,39 @@ int delta_dual_half(pdlp_handle h, int adaptive) { return adaptive ? delta_dual_
 
 // KKT sums of a candidate from the anchors: the current iterate needs at most the pending K'dy; the averaged / previous
 // iterate two float32 products over float32(candidate - current) added to the anchors
-int delta_kkt_local(pdlp_handle h, int which)
+// the current iterate's KKT sums from the anchors; UNSCALE: of the un-preconditioned problem (pdhg.py:157-161)
+template <bool UNSCALE> int delta_kkt_cur(pdlp_handle h)
+{
+    int rc;
+    typedef KktDualEpi<double, UNSCALE> KD;
+    typedef KktPrimalEpi<double, UNSCALE> KP;
+    KD ed{xloc<double>(h, h->ix_cur), (const double*)h->p.c, (const double*)h->p.l, (const double*)h->p.u,
+          UNSCALE ? (const double*)h->p.d_col : nullptr, nullptr};
+    if (!h->dy_folded) {
+        AnchorEpi<KD, true> e{ed, (double*)h->ktyr};
+        if ((rc = launch_mat<float, float, AnchorEpi<KD, true>>(h, true, h->gdy, e, h->partA)) != PDLP_OK) return rc;
+        h->dy_folded = true;
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partA, grid_of(h->sKT, h->nl), 4, h->red, 0);
+    } else {
+        if ((rc = delta_vector_pass(h, h->nl, (const double*)h->ktyr, ed, h->partA)) != PDLP_OK) return rc;
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partA, h->nl > 0 ? grid_for(h->nl) : 0, 4, h->red, 0);
+    }
+    KP ep{yloc<double>(h, h->ix_cur), (const double*)h->p.q, UNSCALE ? (const double*)h->p.d_row : nullptr, nullptr, h->ineq_end};
+    if ((rc = delta_vector_pass(h, h->ml, (const double*)h->kxb[0], ep, h->partB)) != PDLP_OK) return rc;
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partB, h->ml > 0 ? grid_for(h->ml) : 0, 2, h->red, 4);
+    HIP_TRY(hipGetLastError());
+    h->cand_valid[0] = true;
+    return PDLP_OK;
+}
+
+int delta_kkt_local(pdlp_handle h, int which, int unscaled)
 {
     int rc;
     if (!h->anchors_valid && (rc = delta_refresh(h)) != PDLP_OK) return rc;
     typedef KktDualEpi<double, false> KD;
     typedef KktPrimalEpi<double, false> KP;
-    if (which == PDLP_CUR) {
-        KD ed{xloc<double>(h, h->ix_cur), (const double*)h->p.c, (const double*)h->p.l, (const double*)h->p.u, nullptr, nullptr};
-        if (!h->dy_folded) {
-            AnchorEpi<KD, true> e{ed, (double*)h->ktyr};
-            if ((rc = launch_mat<float, float, AnchorEpi<KD, true>>(h, true, h->gdy, e, h->partA)) != PDLP_OK) return rc;
-            h->dy_folded = true;
-            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partA, grid_of(h->sKT, h->nl), 4, h->red, 0);
-        } else {
-            if ((rc = delta_vector_pass(h, h->nl, (const double*)h->ktyr, ed, h->partA)) != PDLP_OK) return rc;
-            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partA, h->nl > 0 ? grid_for(h->nl) : 0, 4, h->red, 0);
-        }
-        KP ep{yloc<double>(h, h->ix_cur), (const double*)h->p.q, nullptr, nullptr, h->ineq_end};
-        if ((rc = delta_vector_pass(h, h->ml, (const double*)h->kxb[0], ep, h->partB)) != PDLP_OK) return rc;
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, h->stream, h->partB, h->ml > 0 ? grid_for(h->ml) : 0, 2, h->red, 4);
-        HIP_TRY(hipGetLastError());
-        h->cand_valid[0] = true;
-        return PDLP_OK;
-    }
+    if (which == PDLP_CUR) return unscaled ? delta_kkt_cur<true>(h) : delta_kkt_cur<false>(h);
+    if (unscaled) return PDLP_ERR_STATE;                  // (the driver evaluates the un-scaled problem at the current iterate only)
     if (!h->dy_folded) {
         FoldEpi f{(double*)h->ktyr};
         if ((rc = launch_mat<float, float, FoldEpi>(h, true, h->gdy, f, h->partA)) != PDLP_OK) return rc;
@@ -999,7 +1008,7 @@ int read_last_rowptr(const int32_t* rp, int64_t rows, int64_t* nnz, hipStream_t 
 // ================================================================================================
 extern "C" {
 
-int pdlp_abi_version(void) { return 9; }   // 9: pdlp_attach_sorted; 8: running products, pdlp_flush_average(h, adaptive); 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
+int pdlp_abi_version(void) { return 10; }  // 10: pdlp_set_anchors; 9: pdlp_attach_sorted; 8: running products, pdlp_flush_average(h, adaptive); 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
 
 const char* pdlp_strerror(int code)
 {
@@ -1560,7 +1569,7 @@ int pdlp_kkt_local(pdlp_handle h, int which, int unscaled)
 {
     if (!h || which < PDLP_CUR || which > PDLP_PREV) return PDLP_ERR_INVALID;
     if (unscaled && (!h->p.d_col || !h->p.d_row)) return PDLP_ERR_STATE;
-    if (h->delta) return unscaled ? PDLP_ERR_STATE : delta_kkt_local(h, which);
+    if (h->delta) return delta_kkt_local(h, which, unscaled);
     return DISPATCH(h, kkt_local_t, h, which, unscaled);
 }
 
@@ -1721,6 +1730,17 @@ int pdlp_refresh_products(pdlp_handle h)
     if (h->delta) return delta_refresh(h);
     if (h->p.dtype == PDLP_F32) return refresh_kx_t<float>(h);
     return refresh_kx_t<double>(h);
+}
+
+int pdlp_set_anchors(pdlp_handle h, const void* kx_local, const void* kty_local)
+{
+    if (!h || !kx_local || !kty_local) return PDLP_ERR_INVALID;
+    if (!h->delta) return PDLP_ERR_STATE;
+    HIP_TRY(hipMemcpyAsync(h->kxb[0], kx_local, (size_t)h->ml * 8, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->ktyr, kty_local, (size_t)h->nl * 8, hipMemcpyDeviceToDevice, h->stream));
+    h->anchors_valid = true; h->dy_folded = true; h->kx_valid = true;
+    h->cand_valid[0] = h->cand_valid[1] = false;
+    return PDLP_OK;
 }
 
 int pdlp_delta_state(pdlp_handle h, int32_t out[3])

@@ -64,11 +64,13 @@ class PdlpEngine:
 
     def __init__(self, m: int, n: int, m_ineq: int, K_rows, KT_rows, c, q, l, u, rows: Tuple[int, int] = None,
                  cols: Tuple[int, int] = None, d_col=None, d_row=None, comm: Optional[Comm] = None, vec_dtype=None,
-                 delta: Optional[bool] = None):
+                 delta: Optional[bool] = None, exact=None, tiles: bool = True):
         """``vec_dtype=torch.float64`` over float32 matrix values selects the mixed precision (``PDLP_MIXED``): float64 vectors,
         products and sums on a float32 matrix (12 -> 8 bytes per non-zero); ``delta`` (default: ``PDLP_DELTA`` in the environment,
         else on) then runs the iterations on the float32 kernels over float32 difference vectors added to float64 anchor
-        products (``pdlp_set_delta`` in include/pdlp_hip.h)."""
+        products (``pdlp_set_delta`` in include/pdlp_hip.h).  ``exact`` = ``(K_rows, KT_rows)`` in float64: the TRUE matrix when the
+        float32 one handed in as ``K_rows`` / ``KT_rows`` is only its rounding (any float64 matrix, a Ruiz-scaled one): the anchors
+        of delta mode are then evaluated with it (a second, float64 CSR handle; ``pdlp_set_anchors``), single GPU only."""
         self.lib = N.load()
         rows = (0, m) if rows is None else rows
         cols = (0, n) if cols is None else cols
@@ -88,9 +90,11 @@ class PdlpEngine:
         self.mixed = self.dtype != self.mat_dtype
         if self.mixed and (self.mat_dtype, self.dtype) != (torch.float32, torch.float64):
             raise ValueError("mixed precision means float32 matrix values under float64 vectors")
-        if self.mixed and (d_col is not None or d_row is not None):
-            raise ValueError("mixed precision needs the matrix entries to be float32 numbers; a Ruiz-scaled matrix is not "
-                             "(use dtype float64 with preconditioning)")
+        if self.mixed and (d_col is not None or d_row is not None) and exact is None:
+            raise ValueError("mixed precision needs the matrix entries to be float32 numbers; a Ruiz-scaled matrix is not: "
+                             "pass the float64 matrix as `exact` (pdlp_algorithm(precision='mixed') does)")
+        if exact is not None and (comm is not None and comm.world > 1):
+            raise ValueError("mixed precision with a separate exact matrix runs on one GPU")
         i32 = lambda t: t.to(device=self.device, dtype=torch.int32).contiguous()
         fv = lambda t, ln: None if t is None else as_vec(t, ln, self.device, self.dtype)
         # keep every tensor the library points into alive
@@ -115,6 +119,10 @@ class PdlpEngine:
         N.check(self.lib.pdlp_create(C.byref(self.h), C.byref(self.prob), self.workspace.data_ptr() + self._ws_off,
                                      nbytes.value), "pdlp_create")
         self._views = {}
+        self._want_tiles = bool(tiles)
+        self.exact = None
+        if exact is not None:          # the true float64 matrix, CSR kernels only: two products per restart
+            self.exact = PdlpEngine(m, n, m_ineq, exact[0], exact[1], c, q, l, u, rows=rows, cols=cols, tiles=False)
         self._sorted = [None, None]
         self._mv_work = {}
         self.tiles = [None, None]
@@ -142,9 +150,9 @@ class PdlpEngine:
         per row 3.3x faster tiled, 500k x 500k with 20 per row 1.35x; with 5 per row the CSR kernel is ahead),
         ``=time`` builds the tiles for every candidate, times both kernels on this device and keeps the faster one
         (not reproducible run to run; tuning only).  ``self.kernels`` records the choice per matrix."""
-        mode = os.environ.get("PDLP_TILED", "auto")
+        mode = os.environ.get("PDLP_TILED", "auto") if self._want_tiles else "0"
         self.kernels = ["csr", "csr"]
-        if os.environ.get("PDLP_SORTED") == "1":            # tests / tuning: sorted row blocks for every matrix the CSR kernel keeps
+        if os.environ.get("PDLP_SORTED") == "1" and self._want_tiles:            # tests / tuning: sorted row blocks for every matrix the CSR kernel keeps
             for transpose in (0, 1):
                 self.attach_sorted(transpose)
         if mode == "0":
@@ -311,6 +319,11 @@ class PdlpEngine:
 
     def refresh_products(self):
         """recompute K x and K'y of the current iterate exactly (float64 accumulation): the anchors of delta mode"""
+        if self.exact is not None:     # the handle's matrix is the float32 rounding of the true one: anchors from the true one
+            x, y = self.get_iterate(N.CUR)
+            kx, kty = self.exact.spmv(x, False), self.exact.spmv(y, True)
+            N.check(self.lib.pdlp_set_anchors(self.h, kx.data_ptr(), kty.data_ptr()), "pdlp_set_anchors")
+            return
         if self.comm is not None:
             self._gather(N.BUF_X_CUR)
             self._gather(N.BUF_Y_CUR)
@@ -328,10 +341,12 @@ class PdlpEngine:
             self.lib.pdlp_destroy(h)
 
     @classmethod
-    def from_full(cls, K: CsrPair, c, q, l, u, m_ineq: int, d_col=None, d_row=None, vec_dtype=None, delta=None) -> "PdlpEngine":
-        """single-GPU engine over a whole problem"""
+    def from_full(cls, K: CsrPair, c, q, l, u, m_ineq: int, d_col=None, d_row=None, vec_dtype=None, delta=None,
+                  exact: Optional[CsrPair] = None) -> "PdlpEngine":
+        """single-GPU engine over a whole problem (``exact``: the float64 matrix of which ``K`` is the float32 rounding)"""
+        ex = None if exact is None else ((exact.rowptr, exact.colidx, exact.val), (exact.t_rowptr, exact.t_colidx, exact.t_val))
         return cls(K.m, K.n, m_ineq, (K.rowptr, K.colidx, K.val), (K.t_rowptr, K.t_colidx, K.t_val), c, q, l, u,
-                   d_col=d_col, d_row=d_row, vec_dtype=vec_dtype, delta=delta)
+                   d_col=d_col, d_row=d_row, vec_dtype=vec_dtype, delta=delta, exact=ex)
 
     # ---- buffers ------------------------------------------------------------------------------------
     def buffer(self, which: int) -> torch.Tensor:
@@ -388,6 +403,8 @@ class PdlpEngine:
     # ---- iterations ---------------------------------------------------------------------------------
     def iterate(self, iters: int, adaptive: bool):
         """`iters` PDHG iterations, no host synchronisation (pdhg.py:76-112)."""
+        if self.exact is not None and self.delta and int(iters) > 0 and not self.delta_state()["anchors_valid"]:
+            self.refresh_products()
         if self.comm is None or self.lib_comm:      # single GPU, or the exchange runs inside the library (RCCL)
             N.check(self.lib.pdlp_iterate(self.h, int(iters), int(adaptive)), "pdlp_iterate")
             return
@@ -428,6 +445,8 @@ class PdlpEngine:
 
     def kkt(self, which: int, omega: float, unscaled: bool = False) -> dict:
         """compute_residuals_and_duality_gap + KKT_error at CUR / AVG / PREV (helpers.py:53-108)."""
+        if self.exact is not None and self.delta and not self.delta_state()["anchors_valid"]:
+            self.refresh_products()
         if self.comm is not None and self.delta:
             # the current iterate is evaluated from the anchors (its pending dy was gathered by the iteration); a candidate
             # from the float32 difference candidate - current, which every rank forms in full

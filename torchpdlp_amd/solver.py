@@ -303,7 +303,9 @@ def pdlp_algorithm(K, m_ineq, c, q, l, u, device=None, max_kkt=100_000, tol=1e-4
     ``precision="mixed"``: float64 vectors, products and sums over a matrix held in float32 -- for tolerances below float32
     resolution (the reference is float32 only) on matrices whose entries are float32 numbers (checked); 8 instead of 12 bytes
     per non-zero, and the iterations run on the float32 kernels over difference vectors (delta mode, include/pdlp_hip.h).
-    ``c, q, l, u`` are taken in float64.  Not with ``precondition`` (a Ruiz-scaled matrix is not float32-valued).
+    ``c, q, l, u`` are taken in float64.  A matrix that is NOT float32-valued (any float64 ``K``, a Ruiz-scaled one with
+    ``precondition=True``) works too, on one GPU: the iterations then run on its float32 rounding and the anchors of delta mode and the
+    termination test are evaluated with the true float64 matrix after every restart.
 
     ``comm`` (a ``Comm``, or ``True`` for the default ``torch.distributed`` group): every rank calls with the SAME
     full problem and the same ``seed``/``b0``; each keeps its row blocks of K and K', the iterations exchange
@@ -315,14 +317,17 @@ def pdlp_algorithm(K, m_ineq, c, q, l, u, device=None, max_kkt=100_000, tol=1e-4
     Kp = CsrPair.from_any(K, device=device)
     dtype = Kp.dtype
     vec_dtype = None
+    exact_K = None
     if precision is not None:
         if precision != "mixed":
             raise ValueError(f"unknown precision {precision!r}")
-        if precondition:
-            raise ValueError("precision='mixed' cannot be combined with precondition=True (use float64)")
         from .engine import values_are_float32
         if not (values_are_float32(Kp.val) and values_are_float32(Kp.t_val)):
-            raise ValueError("precision='mixed' needs a matrix whose entries are float32 numbers")
+            # any float64 matrix (e.g. a Ruiz-scaled one): the iterations run on its float32 ROUNDING (they only multiply
+            # difference vectors), the anchors and the termination test use the true matrix (engine.py, `exact`)
+            if comm is not None and (comm is True or comm.world > 1):
+                raise ValueError("precision='mixed' on a matrix that is not float32-valued runs on one GPU")
+            exact_K = Kp
         Kp = Kp.to(dtype=torch.float32)
         dtype = vec_dtype = torch.float64
     d_col = d_row = None
@@ -349,7 +354,7 @@ def pdlp_algorithm(K, m_ineq, c, q, l, u, device=None, max_kkt=100_000, tol=1e-4
                                                   seed=seed, trace=trace, infeasibility_detect=infeasibility_detect,
                                                   infeas_tol=infeas_tol)
         return gather_solution(eng, x, Kp.n).view(-1, 1), obj, k, n, j, status, total
-    eng = PdlpEngine.from_full(Kp, c, q, l, u, m_ineq, d_col=d_col, d_row=d_row, vec_dtype=vec_dtype)
+    eng = PdlpEngine.from_full(Kp, c, q, l, u, m_ineq, d_col=d_col, d_row=d_row, vec_dtype=vec_dtype, exact=exact_K)
     x, obj, k, n, j, status, total = run_pdlp(eng, max_kkt, tol, verbose, restart_period, precondition, primal_update, adaptive,
                                               time_limit, time_used, x_init, y_init, b0=b0, sigma=sigma, seed=seed, trace=trace,
                                               infeasibility_detect=infeasibility_detect, infeas_tol=infeas_tol)
