@@ -178,10 +178,18 @@ def measure_roofline(args, eng, dt, adaptive, world):
     N.check(eng.lib.pdlp_dual_half(eng.h, int(adaptive)))     #  timed below is the full kernel)
     ms_primal, ms_dual = time_half_steps(eng, adaptive, args.kernel_reps)
     kfam = lambda t: "k_tiled_fused" if eng.tiles[t] is not None else "k_csr_fused"
+
+    def kdesc(t, epi):       # what actually runs for one half-step of this matrix
+        tl = eng.tiles[t]
+        if tl is None:
+            return f"k_csr_fused<{epi}>" + (" over column-sorted row blocks" if "sorted" in eng.kernels[t] else "")
+        if tl.groups > 1:
+            return f"k_tiled_fused x {tl.groups} panel groups + k_rowsum_epilogue<{epi}>"
+        return f"k_tiled_fused<{epi}>" + (" + remainder kernels" if tl.nrem else "")
     if ms_primal >= ms_dual:
-        kname, kms, kbytes = f"{kfam(1)}<PrimalEpi> (K'y + primal update)", ms_primal, b_primal
+        kname, kms, kbytes = f"{kdesc(1, 'PrimalEpi')} (K'y + primal update)", ms_primal, b_primal
     else:
-        kname, kms, kbytes = f"{kfam(0)}<DualEpi> (K xbar + dual update)", ms_dual, b_dual
+        kname, kms, kbytes = f"{kdesc(0, 'DualEpi')} (K xbar + dual update)", ms_dual, b_dual
     achieved = kbytes / (kms * 1e-3) / 1e9
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")       # rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, see profiles/README.md
