@@ -40,16 +40,23 @@ def measure(eng, adaptive=1):
 engines = []
 for spec in libs:                      # "lib.so" or "lib.so:ENV=VALUE" (the variable is set while that engine is built)
     path, _, env = spec.partition(":")
-    if env:
-        os.environ[env.split("=")[0]] = env.split("=")[1]
+    envs = [e.split("=") for e in env.split(",")] if env else []      # "lib.so:A=1,B=2"
+    for kk, vv in envs:
+        os.environ[kk] = vv
     load(path)
     eng = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
     eng.set_step(0.01, 1.0, 1.0, 0)
     eng.iterate(2, True)
     engines.append((spec, eng))
-    if env:
-        os.environ.pop(env.split("=")[0], None)
+    for kk, _ in envs:
+        os.environ.pop(kk, None)
+    print(spec, eng.kernels, flush=True)
+    for tr in (0, 1):
+        t = eng.tiles[tr]
+        if t is not None:
+            a, b, c = t.idx.data_ptr(), t.val.data_ptr(), t.cnt.data_ptr()
+            print(f"   tiles[{tr}] idx {a:#x} val {b:#x} cnt {c:#x}  val-idx {(b - a) / 2**20:.3f} MiB  mod 2MiB: {a % 2**21:#x} {b % 2**21:#x} {c % 2**21:#x}", flush=True)
 for rnd in range(rounds):
     for path, eng in engines:
         pm, dm, pa, da = measure(eng)
-        print(f"round {rnd} {os.path.basename(path):28s} primal median {pm:.4f} mean {pa:.4f} | dual median {dm:.4f} mean {da:.4f} ms", flush=True)
+        print(f"round {rnd} {os.path.basename(path):44s} primal median {pm:.4f} mean {pa:.4f} | dual median {dm:.4f} mean {da:.4f} ms", flush=True)

@@ -52,15 +52,6 @@ template <typename T> __device__ __forceinline__ T shfl_xor_t(T v, int m) { retu
 // 16 lanes, then row_bcast:15 / row_bcast:31 carry the row totals.  All 64 lanes must be active.
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x)
 {
-#ifdef PDLP_SCAN_BC
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);   // row_shr:1 (bound_ctrl: lanes shifted in read 0)
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);   // row_shr:2
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);   // row_shr:4
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);   // row_shr:8
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
-    return x;
-#endif
     x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
     x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
     x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);   // row_shr:4
@@ -68,6 +59,28 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x)
     x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
     x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
     return x;
+}
+
+// two independent inclusive scans at once, written out: the compiler fuses the DPP move into the add for one scan of such
+// a pair but not reliably for the other (18 instead of 6 VALU instructions).  A DPP read of a VGPR needs 2 wait states after
+// the VALU write of it: the other scan's instruction and one s_nop provide them.
+__device__ __forceinline__ void wave_incl_scan2_u32(uint32_t& a, uint32_t& b)
+{
+#ifdef PDLP_NO_SCAN2
+    a = wave_incl_scan_u32(a);
+    b = wave_incl_scan_u32(b);
+#else
+#define PDLP_SCAN_STEP(ctl) "v_add_u32_dpp %0, %0, %0 " ctl "\n\tv_add_u32_dpp %1, %1, %1 " ctl "\n\ts_nop 0\n\t"
+    asm("s_nop 1\n\t"
+        PDLP_SCAN_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        PDLP_SCAN_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        PDLP_SCAN_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        PDLP_SCAN_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        PDLP_SCAN_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        PDLP_SCAN_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        : "+v"(a), "+v"(b));
+#undef PDLP_SCAN_STEP
+#endif
 }
 
 template <typename T> __device__ __forceinline__ T block_sum(T v, T* buf)
@@ -1186,7 +1199,7 @@ int pdlp_attach_tiles(pdlp_handle h, int transpose, const pdlp_tiles* t)
     const int64_t rows = transpose ? h->nl : h->ml;
     const int rpt_max = h->p.dtype == PDLP_F64 ? TileCfg<double, double>::RPT_MAX : TileCfg<float, float>::RPT_MAX;   // (mixed: float32 tiles)
     const int cap_max = h->p.dtype == PDLP_F64 ? TileCfg<double, double>::CAP : TileCfg<float, float>::CAP;
-    if (t->rpt < 1 || t->rpt > rpt_max || t->cap > cap_max || t->lw < 4 || t->lw > 16) return PDLP_ERR_INVALID;
+    if (t->rpt < 1 || t->rpt > rpt_max || t->cap > cap_max || t->lw < 4 || (((uint64_t)t->cap + 8u) << t->lw) > (1ull << 32)) return PDLP_ERR_INVALID;   // (slot, column) must pack into 32 bits
     const int64_t rb = (int64_t)TNT * t->rpt;
     if (t->nblk != (int)((rows + rb - 1) / rb) || t->npanel < 1) return PDLP_ERR_INVALID;
     if (t->groups < 1 || t->groups > h->rs_groups || t->groups > t->npanel) return PDLP_ERR_INVALID;
