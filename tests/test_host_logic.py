@@ -210,3 +210,25 @@ def test_infeasibility_detection_respects_the_pass_cap(golden):
         got = run_pdlp(OracleEngine(o), max_kkt=cap, verbose=False, sigma=sig, infeasibility_detect=True, infeas_tol=1e-9)
         want = orc.pdlp_algorithm(o, max_kkt=cap, sigma=np.float32(sig), infeasibility_detect=True, infeas_tol=1e-9)
         assert got[2:6] == want[2:6]
+
+
+def test_bench_command_line_contract(monkeypatch):
+    """the driver's invocations parse (`--gpus N --steps K --warmup W`), the defaults are the metric's configuration, and the
+    second half of the metric (time to tolerance) is part of a default run; the recorded tight-tolerance runs are readable"""
+    import importlib, json, os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.syspath_prepend(root)
+    monkeypatch.delenv("PDLP_BENCH_N", raising=False)
+    monkeypatch.delenv("PDLP_BENCH_NNZ", raising=False)
+    bench = importlib.import_module("bench")
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert (a.gpus, a.n, a.nnz_per_row, a.mode, a.dtype) == (1, 10_000_000, 100, "adaptive", "f32")
+    assert a.solve_tol == 1e-4 and a.solve_limit > 0
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    a = bench.parse()
+    assert (a.gpus, a.steps, a.warmup) == (8, 20, 5)
+    rec = json.load(open(os.path.join(root, "profiles", "time_to_tol.json")))
+    assert rec["n10000000_k100"]["1e-8"]["seconds"] < 1200            # inside one GPU call of this pool
+    tr = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+    assert set(tr["n10000000_k100_f32_adaptive_g1_tiled"]) >= {"primal", "dual"}
