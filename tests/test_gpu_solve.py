@@ -74,6 +74,27 @@ def test_mixed_precision_with_ruiz_reaches_1e_8_on_afiro():
     assert 0.3 * res[False][1] <= res[True][1] <= 3 * res[False][1]
 
 
+def test_solve_lp_and_cli_in_mixed_precision(tmp_path):
+    """`precision="mixed"` of solve_lp / `--dtype mixed` of the CLI: 1e-8 on afiro with and without Ruiz, from the MPS file"""
+    from torchpdlp_amd.__main__ import main
+    for ruiz in (False, True):
+        res = tp.solve_lp(os.path.join(MPS_DIR, "afiro.mps"), tol=1e-8, precondition=ruiz, primal_weight_update=True,
+                          adaptive_stepsize=True, precision="mixed", seed=3, max_kkt=2_000_000)
+        assert res.status == "Solved" and abs(res.objective - AFIRO_OPT) <= 2e-8 * (1 + 2 * abs(AFIRO_OPT))
+        assert res.x.dtype == torch.float64
+    with pytest.raises(ValueError):
+        tp.solve_lp(os.path.join(MPS_DIR, "afiro.mps"), precision="half")
+    one = tmp_path / "in"
+    one.mkdir()
+    import shutil
+    shutil.copy(os.path.join(MPS_DIR, "afiro.mps"), one / "afiro.mps")
+    rc = main(["--instance_path", str(one), "--output_path", str(tmp_path / "out"), "--adaptive_stepsize", "--primal_weight_update",
+               "--precondition", "--dtype", "mixed", "--tolerance", "1e-8", "--seed", "1", "--max_kkt", "2000000"])
+    assert rc == 0
+    row = list(csv.DictReader(open(tmp_path / "out" / "solver_results.csv")))[0]
+    assert row["Status"] == "Solved" and abs(float(row["Objective"]) - AFIRO_OPT) <= 1e-5
+
+
 def test_cli_writes_the_reference_csv_schema(tmp_path):
     from torchpdlp_amd.__main__ import COLUMNS, main
     rc = main(["--instance_path", MPS_DIR, "--output_path", str(tmp_path), "--adaptive_stepsize", "--primal_weight_update",

@@ -35,7 +35,8 @@ def parse_args(argv=None):
     p.add_argument("--max_kkt", type=int, default=100_000)
     p.add_argument("--time_limit", type=int, default=3600)
     p.add_argument("--fishnet", action="store_true")
-    p.add_argument("--dtype", choices=["fp32", "fp64"], default="fp32", help="fp64 for tolerances below float32 resolution")
+    p.add_argument("--dtype", choices=["fp32", "fp64", "mixed"], default="fp32",
+                   help="for tolerances below float32 resolution: mixed (float32 matrix entries under float64 vectors, the fast way) or fp64")
     p.add_argument("--seed", type=int, default=None, help="pins the power-iteration start vector (unseeded in the reference)")
     p.add_argument("--standard_mps", action="store_true", help="standard meaning of FR/MI/PL/BV bounds instead of the reference's")
     return p.parse_args(argv)
@@ -86,7 +87,7 @@ def main(argv=None) -> int:
             r = solve_lp(problem, tol=args.tolerance, precondition=args.precondition, primal_weight_update=args.primal_weight_update,
                          adaptive_stepsize=args.adaptive_stepsize, max_kkt=args.max_kkt, time_limit=args.time_limit,
                          verbose=args.verbose, dtype=dtype, seed=args.seed, fishnet=args.fishnet, comm=comm,
-                         infeasibility_detect=args.infeasibility_detect)
+                         infeasibility_detect=args.infeasibility_detect, precision="mixed" if args.dtype == "mixed" else None)
             print(f"Solver uses {r.time:.4f} seconds.\nStatus: {r.status}")
             results.append({"File": name, "Objective": f"{r.objective:.6f}", "Iterations (k)": r.iterations, "Restarts (n)": r.restarts,
                             "KKT Passes (j)": r.kkt_passes, "Time (s)": f"{r.time:.4f}", "Status": r.status})      # main.py:142-150

@@ -35,17 +35,24 @@ def solve_lp(problem: Union[str, os.PathLike, tuple], device=None, tol: float = 
              primal_weight_update: bool = False, adaptive_stepsize: bool = False, max_kkt: int = 100_000,
              time_limit: float = 3600, verbose: bool = False, restart_period: int = 40, dtype=torch.float32,
              seed: Optional[int] = None, compat: bool = True, x_init=None, y_init=None, trace=None,
-             fishnet: bool = False, comm=None, infeasibility_detect: bool = False, infeas_tol: float = 1e-4) -> LPResult:
+             fishnet: bool = False, comm=None, infeasibility_detect: bool = False, infeas_tol: float = 1e-4,
+             precision: Optional[str] = None) -> LPResult:
     """Solve ``min c'x, K[:m_ineq]x >= q[:m_ineq], K[m_ineq:]x = q[m_ineq:], l <= x <= u`` on the current HIP device.
 
     ``problem`` is an MPS path or ``(c, K, q, m_ineq, l, u)`` with ``K`` dense / COO / scipy-sparse / ``CsrPair``.
     Flags carry the reference CLI's names (main.py:11-39).  ``dtype=torch.float64`` is the mode for tolerances
-    below float32 resolution (the reference is float32 only).  ``infeasibility_detect`` runs the reference's detector
+    below float32 resolution (the reference is float32 only); ``precision="mixed"`` (the problem is then read in float64) is the
+    fast way there: float32 matrix entries under float64 vectors, iterations on the float32 kernels (``pdlp_algorithm``).
+    ``infeasibility_detect`` runs the reference's detector
     (enhancements.py:80-161) after every iteration, with its behaviour as it is.  Under ``torchrun`` (one process per GPU, process
     group initialised) pass ``comm=True``: every rank reads the same problem, keeps its row blocks of K and K', and
     all return the full solution.
     """
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if precision is not None:
+        if precision != "mixed":
+            raise ValueError(f"unknown precision {precision!r}")
+        dtype = torch.float64
     if isinstance(problem, (str, os.PathLike)):
         c, K, q, m_ineq, l, u = mps_to_standard_form(os.fspath(problem), device=device, verbose=verbose, compat=compat, dtype=dtype)
     else:
@@ -66,7 +73,7 @@ def solve_lp(problem: Union[str, os.PathLike, tuple], device=None, tol: float = 
         Ks, m_ineq, cs, qs, ls, us, device, max_kkt=max_kkt, tol=tol, verbose=verbose, restart_period=restart_period,
         precondition=precondition, primal_update=primal_weight_update, adaptive=adaptive_stepsize,
         data_precond=data_precond, time_limit=time_limit, time_used=time_used, x_init=x_init, y_init=y_init, seed=seed,
-        trace=trace, comm=comm, infeasibility_detect=infeasibility_detect, infeas_tol=infeas_tol)
+        trace=trace, comm=comm, infeasibility_detect=infeasibility_detect, infeas_tol=infeas_tol, precision=precision)
     if precondition:        # the reference returns the scaled iterate (quirk Q4); solve_lp un-scales: x = D_col x_s (pdhg.py:161)
         x = data_precond[0].view(-1, 1).to(x.dtype) * x
     return LPResult(x, obj, k, n, j, status, total)
