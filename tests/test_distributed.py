@@ -406,6 +406,19 @@ def _rccl_world1_worker(rank, world, port, ret):
                     outs.append((x.clone(), y.clone(), e.scalars()["eta"], e.kkt(N.CUR, 1.0)["kkt"]))
                 assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
                 assert outs[0][2] == outs[1][2] and outs[0][3] == outs[1][3]
+        # per-shard generation + distributed transpose under RCCL (device-side count exchange, all_to_all_single with uneven
+        # splits): with one rank the shard is the whole instance, entry for entry the one gen_lp builds
+        from torchpdlp_amd.distributed import gen_lp_shard
+        es = gen_lp_shard(70_000, 90_000, 7, 5, comm, dev)
+        lp = gen_lp(70_000, 90_000, 7, seed=5, device=dev)
+        ef = tp.PdlpEngine.from_full(tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val), lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
+        outs = []
+        for e in (ef, es):
+            e.set_step(0.02, 1.1, 1.0, 0)
+            e.iterate(7, True)
+            x, y = e.get_iterate(N.CUR)
+            outs.append((x[:lp.n].clone(), y[:lp.m].clone(), e.kkt(N.CUR, 1.0)["kkt"]))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()
