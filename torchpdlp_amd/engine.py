@@ -287,6 +287,11 @@ class PdlpEngine:
         C.memmove(idbuf, raw[:128], 128)
         if ok and self.lib.pdlp_comm_init(self.h, cpath, idbuf, rank, world) != 0:
             ok = 0
+        # every rank must have a communicator before any of them enters a collective on it (a rank that failed to initialise
+        # would leave the others waiting in the round trip below)
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        ok = int(flag)
         if ok:          # round trip: all-gather of a full-length float vector and the 8-double all-reduce
             try:
                 dx, red = self.buffer(N.BUF_DX), self.buffer(N.BUF_RED)
