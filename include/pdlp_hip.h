@@ -92,7 +92,8 @@ typedef struct pdlp_problem {
  * three (float64) 32-bit words of 4-bit item counts (<= 15) of the thread's rows (nibble i = row i of the thread);
  * any 64 consecutive rows (one i of one wave) may hold at most 255 items of a tile -- the kernel scans the lanes'
  * counts in 8-bit fields.  float32 (and PDLP_MIXED, whose tiles are float32): rpt <= 40, cap <= 16384; float64: rpt <= 24,
- * cap <= 8192. */
+ * cap <= 8192.  (slot, column) must pack into 32 bits: (cap + 8) << lw <= 2^32, i.e. lw <= 17 at the full float32 capacity
+ * (the builder uses 16: a 256 KB panel stays L2-resident on every XCD and keeps the gathered lines dense). */
 typedef struct pdlp_tiles {
     int32_t lw, rpt, cap;       /* panel = 2^lw columns; rows per thread              ; most items per tile  */
     int32_t nblk, npanel;       /* row blocks, column panels                                               */
