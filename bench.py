@@ -17,7 +17,8 @@ on: 10M x 10M, density 1e-5 (100 non-zeros per row), float32 like the reference;
 With N > 1 the same instance is sharded (row blocks of K and K'; every rank generates its own shard), so scaling is strong.
 
 Also reports, in the same JSON line:
-  roofline     algorithmic HBM bytes of the dominant kernel per launch / its mean duration (HIP events)
+  roofline     algorithmic HBM bytes of the dominant kernel per launch / its mean duration (HIP events); `traffic` (PMC bytes per
+               launch) and `measured_read_ceiling` (a streaming-read probe of this GPU) are recorded runs from profiles/
   cpu_baseline the CPU oracle (C port, OpenMP) on a bounded sample of the same workload, rank 0, N=1 only
   time_to_tol  the second half of the metric: after the timed region the same LP is solved from zero to --solve-tol (default
                1e-4, the reference's default; N=1 only); "recorded" carries the separately measured 1e-8 runs of profiles/
@@ -198,17 +199,22 @@ def measure_roofline(args, eng, dt, adaptive, world):
         kname, kms, kbytes = f"{kdesc(0, 'DualEpi')} (K xbar + dual update)", ms_dual, b_dual
     achieved = kbytes / (kms * 1e-3) / 1e9
     traffic = None
+    ceiling = None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")       # rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, see profiles/README.md
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
             key = f"n{args.n}_k{args.nnz_per_row}_{args.dtype}_{args.mode}_g{world}_{kfam(1).split('_')[1]}"
             traffic = tj.get(key, {}).get("primal" if ms_primal >= ms_dual else "dual")
+            ceiling = tj.get("read_ceiling")
         except Exception:
             traffic = None
     roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, launch_ms=round(kms, 4),
                     algorithmic_bytes=int(kbytes), other_kernel_ms=round(min(ms_primal, ms_dual), 4))
+    if ceiling:      # the device's measured streaming-read ceiling beside the nominal peak (a recorded probe run, not this run)
+        roofline["measured_read_ceiling"] = {"value": ceiling["GBs"], "unit": "GB/s", "frac": round(achieved / ceiling["GBs"], 4),
+                                             "source": ceiling["source"]}
     return roofline
 
 
