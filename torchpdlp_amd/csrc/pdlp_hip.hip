@@ -332,7 +332,7 @@ int launch_mat(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* 
         const T* extra = nullptr;
         if (s.t.rem_rows_n > 0) {
             T* ex = (T*)(sizeof(T) == 4 && h->es == 8 ? s.t.rem_extra_f32 : s.t.rem_extra);
-            hipLaunchKernelGGL((k_rem_segments<T, TV>), dim3(grid_for((int64_t)s.t.rem_segs_n * 64)), dim3(BLOCK), 0, h->stream, s.t.rem_segs_n,
+            hipLaunchKernelGGL((k_rem_segments<T, TV>), dim3(grid_for((int64_t)s.t.rem_segs_n * 8)), dim3(BLOCK), 0, h->stream, s.t.rem_segs_n,
                                s.t.rem_sptr, s.t.rem_col, (const TV*)s.t.rem_val, (const T*)vin, (T*)s.t.rem_work);
             hipLaunchKernelGGL((k_rem_rows<T>), dim3(grid_for((int64_t)s.t.rem_rows_n * 8)), dim3(BLOCK), 0, h->stream, s.t.rem_rows_n, s.t.rem_rows,
                                s.t.rem_rptr, (const T*)s.t.rem_work, ex);
