@@ -53,7 +53,7 @@ GROUP = 256          # tiles are padded to whole groups of 4 x 64 items (interle
 NCU = 512            # two workgroups per CU at a time: row blocks are sized to fill whole rounds
 LMAX = 15            # items of one row in one tile (4-bit counts)
 GMAX = 255           # items of 64 consecutive rows (one i of one wave) in one tile (8-bit scan fields)
-SEG = 512            # items per remainder segment (one wave: 8 per lane)
+SEG = 512            # items per remainder segment (eight lanes: 64 per lane, in batches of eight)
 
 
 @dataclass
