@@ -15,43 +15,78 @@ For steps a multiple of 40 that is steps / elapsed exactly.  All three raw numbe
 The LP is resident in HBM before the clock starts.  Default workload = the one the metric is quoted
 on: 10M x 10M, density 1e-5 (100 non-zeros per row), float32 like the reference; it fits one GPU.
 With N > 1 the same instance is sharded (row blocks of K and K'; every rank generates its own shard), so scaling is strong.
+Started as a plain ``python bench.py --gpus N`` (no WORLD_SIZE in the environment) with N > 1, the script starts the N rank
+processes itself (``spawn_ranks``: a child ``python -m torch.distributed.run`` -- before this process has touched a GPU, never an
+exec), relays rank 0's JSON line and exits non-zero if any rank fails.  ``--ruiz`` benchmarks BASELINE configs[4]: the sharded
+Ruiz sweeps first (no rank holds the whole LP), then the same timed region on the scaled problem.
 
 Also reports, in the same JSON line:
   roofline     algorithmic HBM bytes of the dominant kernel per launch / its mean duration (HIP events); `traffic` (PMC bytes per
                launch) and `measured_read_ceiling` (a streaming-read probe of this GPU) are recorded runs from profiles/
   cpu_baseline the CPU oracle (C port, OpenMP) on a bounded sample of the same workload, rank 0, N=1 only
   time_to_tol  the second half of the metric: after the timed region the same LP is solved from zero to --solve-tol (default
-               1e-4, the reference's default; N=1 only); "recorded" carries the separately measured 1e-8 runs of profiles/
+               1e-4, the reference's default; every N); "recorded" carries the separately measured 1e-8 runs of profiles/
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torchpdlp_amd as tp                                     # noqa: E402
-from torchpdlp_amd import _native as N                         # noqa: E402
-from torchpdlp_amd.distributed import gen_lp_shard             # noqa: E402
-from torchpdlp_amd.solver import PdhgDriver, estimate_sigma    # noqa: E402
-
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
-def parse():
+def spawn_ranks(gpus: int, argv, script: str = None, env: dict = None) -> int:
+    """Start `gpus` rank processes of `script` (this file) under torch.distributed.run as a CHILD process, pass rank 0's JSON
+    line through and return the exit code: 0 only if every rank finished and a line came back.  The caller has not touched
+    the GPU yet, and nothing is exec'ed: the parent stays a plain Python process that waits."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(gpus)}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC (RCCL between processes on this host driver)
+    e.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=e)
+    lines = []
+    for line in proc.stdout:
+        lines.append(line.rstrip("\n"))
+    rc = proc.wait()
+    result = [ln for ln in lines if ln.startswith("{") and '"metric"' in ln]
+    for ln in lines:
+        if ln not in result:
+            print(ln, file=sys.stderr)
+    if rc != 0:
+        print(f"bench.py: the {gpus}-rank run failed (exit code {rc})", file=sys.stderr)
+        return rc if 0 < rc < 256 else 1
+    if not result:
+        print("bench.py: the ranks finished without a result line", file=sys.stderr)
+        return 1
+    print(result[-1], flush=True)
+    return 0
+
+
+def parse(argv=None):
     p = argparse.ArgumentParser()
-    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--gpus", type=int, default=None, help="ranks (= GPUs); default: WORLD_SIZE of the launcher, else 1")
+    p.add_argument("--ruiz", action="store_true", help="BASELINE configs[4]: Ruiz-precondition the LP first (sharded sweeps when N > 1)")
+    p.add_argument("--lib-comm", choices=["auto", "off"], default="auto",
+                   help="N > 1 under RCCL: try the exchange inside the library (cross-checked against the torch.distributed loop, "
+                        "falls back on any difference) or stay on the torch.distributed loop")
     p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=40)
     p.add_argument("--n", type=int, default=int(os.environ.get("PDLP_BENCH_N", 10_000_000)))
     p.add_argument("--m", type=int, default=None)
     p.add_argument("--nnz-per-row", type=int, default=int(os.environ.get("PDLP_BENCH_NNZ", 100)))
     p.add_argument("--mode", choices=["adaptive", "fixed"], default="adaptive")
-    p.add_argument("--dtype", choices=["f32", "f64"], default="f32")
+    p.add_argument("--dtype", choices=["f32", "f64", "mixed"], default="f32",
+                   help="mixed: float32 matrix under float64 vectors, delta mode (the path to 1e-8)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--solve-tol", type=float, default=1e-4,
                    help="after the timed region: a full restarted solve of the same LP to this relative KKT tolerance (the second half "
@@ -59,13 +94,16 @@ def parse():
     p.add_argument("--solve-limit", type=float, default=120.0, help="time limit of that solve, seconds")
     p.add_argument("--cpu-sample-rows", type=int, default=500_000)
     p.add_argument("--kernel-reps", type=int, default=20)
-    return p.parse_args()
+    p.add_argument("--check-periods", type=int, default=5, help="restart periods the cost of one check is averaged over (after the timed region)")
+    return p.parse_args(argv)
 
 
-def algorithmic_bytes(n, m, nnz, sv, si, adaptive):
-    """SURVEY.md section 8d, per launch of each half-step kernel (each array counted once)."""
-    primal = nnz * (sv + si) + (n + 1) * si + m * sv + 8 * n * sv          # K' stream, gather y, x c l u | x+ xbar | sum RMW
-    dual = nnz * (sv + si) + (m + 1) * si + n * sv + 5 * m * sv            # K stream, gather xbar, y q | y+ | sum RMW
+def algorithmic_bytes(n, m, nnz, sv, si, adaptive, sm=None):
+    """SURVEY.md section 8d, per launch of each half-step kernel (each array counted once); sv = bytes of a vector entry,
+    sm = bytes of a matrix value (they differ in mixed precision)"""
+    sm = sv if sm is None else sm
+    primal = nnz * (sm + si) + (n + 1) * si + m * sv + 8 * n * sv          # K' stream, gather y, x c l u | x+ xbar | sum RMW
+    dual = nnz * (sm + si) + (m + 1) * si + n * sv + 5 * m * sv            # K stream, gather xbar, y q | y+ | sum RMW
     if adaptive:
         dual += 2 * m * sv                                                 # cached K x read + write
     return primal, dual
@@ -175,12 +213,12 @@ def cpu_baseline(args, sv_dtype):
 
 def measure_roofline(args, eng, dt, adaptive, world):
     """roofline of the dominant kernel (per launch, this rank's shard): algorithmic bytes / mean HIP-event duration"""
-    sv, si = (4 if dt == torch.float32 else 8), 4
+    sv, sm, si = eng.dtype.itemsize, eng.mat_dtype.itemsize, 4
     nl, ml = eng.nl, eng.ml
     nnz_k = int(eng.K[2].numel())
     nnz_kt = int(eng.KT[2].numel())
-    b_primal, _ = algorithmic_bytes(nl, eng.m, nnz_kt, sv, si, adaptive)
-    _, b_dual = algorithmic_bytes(eng.n, ml, nnz_k, sv, si, adaptive)
+    b_primal, _ = algorithmic_bytes(nl, eng.m, nnz_kt, sv, si, adaptive, sm)
+    _, b_dual = algorithmic_bytes(eng.n, ml, nnz_k, sv, si, adaptive, sm)
     N.check(eng.lib.pdlp_primal_half(eng.h, int(adaptive)))   # (leaves no K'y behind from a restart check: the primal half-step
     N.check(eng.lib.pdlp_dual_half(eng.h, int(adaptive)))     #  timed below is the full kernel)
     ms_primal, ms_dual = time_half_steps(eng, adaptive, args.kernel_reps)
@@ -218,9 +256,66 @@ def measure_roofline(args, eng, dt, adaptive, world):
     return roofline
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+def _imports():
+    """torch and the package, only in a process that is going to compute (after the decision to spawn ranks)"""
+    global torch, tp, N, PdhgDriver, estimate_sigma
+    import torch
+    import torchpdlp_amd as tp
+    from torchpdlp_amd import _native as N
+    from torchpdlp_amd.solver import PdhgDriver, estimate_sigma
+
+
+def build_engine(args, comm, dev, dt):
+    """the LP resident in HBM: (engine, nnz of the whole problem, set-up notes)"""
+    m = args.m or args.n
+    notes = {}
+    precision = "mixed" if args.dtype == "mixed" else None
+    if comm is None:
+        lp = tp.gen_lp(args.n, m, args.nnz_per_row, seed=0, device=dev, dtype=torch.float64 if precision else dt)
+        K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
+        nnz = K.nnz
+        c, q, l, u, d_col, d_row, exact = lp.c, lp.q, lp.l, lp.u, None, None, None
+        if args.ruiz:
+            K, c, q, l, u, data, secs = tp.ruiz_precondition(lp.c, K, lp.q, lp.l, lp.u, device=dev)
+            d_col, d_row = data[0], data[1]
+            notes["ruiz_seconds"] = round(secs, 2)
+        vec = None
+        if precision:
+            from torchpdlp_amd.engine import values_are_float32
+            if not (values_are_float32(K.val) and values_are_float32(K.t_val)):
+                exact = K
+            K, vec = K.to(dtype=torch.float32), torch.float64
+        eng = tp.PdlpEngine.from_full(K, c, q, l, u, lp.m_ineq, d_col=d_col, d_row=d_row, vec_dtype=vec, exact=exact)
+        del K, lp
+    else:
+        # the same seeded instance, but every rank generates only its own rows of K and receives its rows of K' through the
+        # distributed transpose; Ruiz runs on the shards: no rank ever holds the whole LP (SURVEY 8d cfg 4 / 5)
+        from torchpdlp_amd.distributed import gen_lp_shard
+        eng = gen_lp_shard(args.n, m, args.nnz_per_row, 0, comm, dev, dt, precision=precision, precondition=args.ruiz)
+        tn = torch.tensor([eng.nnz_local], dtype=torch.int64, device=dev)
+        comm.all_reduce_sum(tn)
+        nnz = int(tn)
+        if args.ruiz:
+            notes["ruiz_seconds"], notes["ruiz_sweeps"] = round(eng.ruiz_seconds, 2), eng.ruiz_sweeps
+    return eng, nnz, notes
+
+
+def main(argv=None):
+    args = parse(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus is None:
+        args.gpus = int(env_world) if env_world else 1
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        return 2
+    if env_world is None and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (it has not initialised any GPU)
+        return spawn_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        return 2
+    _imports()
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("PDLP_DIST_BACKEND", "nccl")       # "gloo" + PDLP_BENCH_SHARE_GPU=1: rehearsal on a 1-GPU box
@@ -236,26 +331,24 @@ def main():
         else:
             dist.init_process_group(backend)
         comm = tp.Comm()
+        assert comm.world == world == args.gpus
     m = args.m or args.n
     dt = torch.float32 if args.dtype == "f32" else torch.float64
     adaptive = args.mode == "adaptive"
 
     t_setup = time.time()
-    if comm is None:
-        lp = tp.gen_lp(args.n, m, args.nnz_per_row, seed=0, device=dev, dtype=dt)
-        K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
-        nnz = K.nnz
-        eng = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
-        del K, lp
-    else:
-        # the same seeded instance, but every rank generates only its own rows of K and receives its rows of K' through the
-        # distributed transpose: no rank ever holds the whole LP (SURVEY 8d cfg 4)
-        eng = gen_lp_shard(args.n, m, args.nnz_per_row, 0, comm, dev, dt)
-        tn = torch.tensor([eng.nnz_local], dtype=torch.int64, device=dev)
-        comm.all_reduce_sum(tn)
-        nnz = int(tn)
+    eng, nnz, notes = build_engine(args, comm, dev, dt)
     torch.cuda.empty_cache()
-    drv = PdhgDriver(eng, restart_period=40, primal_update=True, adaptive=adaptive, tol=1e-4)
+    exchange = None
+    if comm is not None:
+        # which code drives the exchange between the half-steps: the library's own RCCL communicator (one C call per restart
+        # period) if every rank can set it up AND its iterations equal the torch.distributed loop's bit for bit; else that loop
+        exchange = {"path": "torch.distributed loop", "backend": comm.backend, "ranks": comm.world}
+        if args.lib_comm == "auto" and comm.backend == "nccl":
+            on = eng.enable_library_comm(timeout=float(os.environ.get("PDLP_COMM_TIMEOUT", "90")), cross_check=True)
+            exchange["path"] = "library RCCL communicator (pdlp_iterate)" if on else "torch.distributed loop (library path declined)"
+            exchange["log"] = eng.lib_comm_log
+    drv = PdhgDriver(eng, restart_period=40, primal_update=True, adaptive=adaptive, precondition=args.ruiz, tol=1e-4)
     sigma = estimate_sigma(eng, power_iters=20, seed=0)
     drv.start(sigma)
     setup_s = time.time() - t_setup
@@ -270,6 +363,13 @@ def main():
             comm.dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(v):
+        if comm is None:
+            return v
+        tt = torch.tensor([v], dtype=torch.float64, device=dev)
+        comm.all_reduce_max(tt)
+        return float(tt)
+
     period = drv.period
     run(args.warmup)
     extra = (-drv.tt) % period                 # untimed: up to (and including) the next restart check
@@ -280,22 +380,17 @@ def main():
     t0 = time.time()
     run(args.steps)
     fence()
-    elapsed = time.time() - t0
+    elapsed = max_over_ranks(time.time() - t0)
     checks_in, restarts_in = drv.checks - checks0, drv.n - restarts0
-    if comm is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        comm.dist.all_reduce(tt, op=comm.dist.ReduceOp.MAX)
-        elapsed = float(tt)
-    # the cost of one restart check, measured (wall clock, synchronised) on the next whole period(s)
+    # the cost of one restart check INCLUDING the restart work at the rate restarts fire (wall clock, synchronised), measured
+    # over the next whole periods: a check that evaluates the previous iterate too costs 2 products more than one that does
+    # not, and a restart adds its vector passes -- several periods average that out
     run((-drv.tt) % period)
-    drv.check_seconds, c1 = 0.0, drv.checks
-    run(2 * period)
-    check_s = drv.check_seconds / max(1, drv.checks - c1)
+    drv.check_seconds, c1, r1 = 0.0, drv.checks, drv.n
+    run(args.check_periods * period)
+    checks_m, restarts_m = drv.checks - c1, drv.n - r1
+    check_s = max_over_ranks(drv.check_seconds / max(1, checks_m))
     drv.check_seconds = None
-    if comm is not None:
-        tt = torch.tensor([check_s], dtype=torch.float64, device=dev)
-        comm.dist.all_reduce(tt, op=comm.dist.ReduceOp.MAX)
-        check_s = float(tt)
     norm_elapsed = elapsed + (args.steps / period - checks_in) * check_s
 
     try:
@@ -306,30 +401,37 @@ def main():
     out = {
         "metric": "PDHG iterations/sec", "value": round(args.steps / norm_elapsed, 3), "unit": "iterations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(norm_elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64 vectors / f32 matrix" if args.dtype == "mixed" else args.dtype,
+        "data": "synthetic",
         "config": {"workload": f"synthetic random feasible LP {args.n}x{m}, {args.nnz_per_row} nnz/row "
-                               f"(density {args.nnz_per_row / args.n:.1e}), gen_lp recipe 'box' seed 0",
+                               f"(density {args.nnz_per_row / args.n:.1e}), gen_lp recipe 'box' seed 0"
+                               + (", Ruiz-preconditioned (20 sweeps, eps 1e-6)" if args.ruiz else ""),
                    "nnz": nnz, "step": f"{args.mode} PDHG iteration at the reference's restart cadence (one check = 3 KKT evaluations per "
                                        f"{period} iterations, + the restart work when one fires), normalised to steps/{period} checks",
                    "primal_weight_update": True, "kernels": {"K": eng.kernels[0], "K'": eng.kernels[1]},
                    "parallelism": "single GPU" if world == 1 else
-                   f"row-block shards of K and K' over {world} GPUs, all-gather(xbar), all-gather(y) per iteration "
+                   f"{world} ranks: row-block shards of K and K', all-gather(xbar), all-gather(y) per iteration "
                    f"({'RCCL' if comm.backend == 'nccl' else comm.backend + ' (rehearsal, not RCCL)'})"},
         "timing": {"elapsed_s": round(elapsed, 6), "raw_value": round(args.steps / elapsed, 3), "checks_in_timed_region": checks_in,
                    "restarts_in_timed_region": restarts_in, "check_ms": round(check_s * 1e3, 3),
+                   "check_ms_measured_over": {"checks": checks_m, "restarts": restarts_m},
                    "warmup_done": args.warmup + extra, "normalised_elapsed_s": round(norm_elapsed, 6)},
         "roofline": roofline,
         "setup_s": round(setup_s, 1),
     }
-    if world == 1 and args.solve_tol > 0:
+    if exchange is not None:
+        out["config"]["exchange"] = exchange
+    out["config"].update(notes)
+    if args.solve_tol > 0:
         # time to tolerance (untimed part of the run, the engine of the timed region re-started from zero): the reference's default
         # tolerance fits a bench run; tighter ones are separate runs (tools/time_to_tol.py), recorded in profiles/time_to_tol.json
         try:
             from torchpdlp_amd.solver import run_pdlp
             _, obj, it, nr, jj, status, secs = run_pdlp(eng, tol=args.solve_tol, verbose=False, primal_update=True, adaptive=adaptive,
-                                                        time_limit=args.solve_limit, seed=0, power_iters=100)
-            ttt = {"tol": args.solve_tol, "seconds": round(secs, 2), "iterations": int(it), "restarts": int(nr), "kkt_passes": int(jj),
-                   "status": status, "objective": float(obj), "includes": "power iteration (100 steps), all restart checks"}
+                                                        precondition=args.ruiz, time_limit=args.solve_limit, seed=0, power_iters=100)
+            ttt = {"tol": args.solve_tol, "seconds": round(max_over_ranks(secs), 2), "iterations": int(it), "restarts": int(nr),
+                   "kkt_passes": int(jj), "status": status, "objective": float(obj), "n_gpus": world,
+                   "includes": "power iteration (100 steps), all restart checks" + ("; Ruiz set-up reported separately" if args.ruiz else "")}
             rec = os.path.join(ROOT, "profiles", "time_to_tol.json")
             if os.path.exists(rec):
                 ttt["recorded"] = json.load(open(rec)).get(f"n{args.n}_k{args.nnz_per_row}", None)
@@ -340,7 +442,7 @@ def main():
         del drv, eng
         torch.cuda.empty_cache()
         try:
-            out["cpu_baseline"] = cpu_baseline(args, dt)
+            out["cpu_baseline"] = cpu_baseline(args, torch.float64 if args.dtype != "f32" else dt)
         except Exception as e:
             out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     if rank == 0:
@@ -348,7 +450,8 @@ def main():
     if comm is not None:
         comm.dist.barrier()
         comm.dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

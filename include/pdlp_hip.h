@@ -203,11 +203,14 @@ int pdlp_fixed_advance(pdlp_handle h, int iters);
  * torchpdlp_amd/distributed.py).  The reference is single-device, so these have no counterpart there; SURVEY.md 8b sketched
  * them as pdlp_create_sharded(..., ncclComm_t, rank, nranks).  RCCL is resolved with dlopen on first use (rccl_path: the
  * librccl.so the process already has loaded, e.g. PyTorch's; NULL = search the default names), so single-GPU use never needs it.
+ * pdlp_comm_load: dlopen + symbol lookup only (rank local, no communication): call it on every rank and agree on the results
+ *   BEFORE any rank enters pdlp_comm_init, which is collective -- a rank that cannot load RCCL would leave the others waiting.
  * pdlp_comm_unique_id: rank 0 creates the id, the caller broadcasts its 128 bytes to all ranks (any transport).
  * pdlp_comm_init: ncclCommInitRank on the handle's device.  From then on pdlp_iterate runs whole sharded iterations --
  *   half-steps, the all-gathers of xbar and y (float32 differences in delta mode) overlapped with the local panels' products,
  *   and the 3-double all-reduce of the step-size rule -- on the handle's stream with no host work in between.
  * pdlp_comm_all_gather / pdlp_comm_all_reduce_red: the same collectives for the caller-driven parts (KKT passes, set-up). */
+int pdlp_comm_load(const char* rccl_path);
 int pdlp_comm_unique_id(const char* rccl_path, void* id128);
 int pdlp_comm_init(pdlp_handle h, const char* rccl_path, const void* id128, int rank, int nranks);
 int pdlp_comm_all_gather(pdlp_handle h, int which /* PDLP_BUF_* of a full-length vector */);

@@ -1,0 +1,85 @@
+"""bench.py as its own launcher (CPU): ``python bench.py --gpus N`` without a launcher's environment must start N rank processes as
+children -- before this process touches a GPU, never by exec -- relay rank 0's JSON line, and fail when any rank fails."""
+import json
+import os
+import sys
+import textwrap
+
+import pytest
+
+import bench
+
+
+def _script(tmp_path, body):
+    p = tmp_path / "ranks.py"
+    p.write_text(textwrap.dedent(body))
+    return str(p)
+
+
+def test_spawn_ranks_relays_rank0_line(tmp_path, capfd):
+    script = _script(tmp_path, """
+        import json, os, sys
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        assert os.environ["MASTER_ADDR"] == "127.0.0.1" and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+        print(f"noise from rank {rank}")
+        if rank == 0:
+            print(json.dumps({"metric": "PDHG iterations/sec", "n_gpus": world, "argv": sys.argv[1:]}))
+    """)
+    rc = bench.spawn_ranks(2, ["--steps", "7"], script=script)
+    out, err = capfd.readouterr()
+    assert rc == 0
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1                                   # exactly the JSON line on stdout; everything else goes to stderr
+    got = json.loads(lines[0])
+    assert got["n_gpus"] == 2 and got["argv"] == ["--steps", "7"]
+    assert "noise from rank 1" in err
+
+
+def test_spawn_ranks_fails_when_a_rank_fails(tmp_path, capfd):
+    script = _script(tmp_path, """
+        import json, os, sys
+        if int(os.environ["RANK"]) == 1:
+            sys.exit(3)
+        print(json.dumps({"metric": "x"}))
+    """)
+    rc = bench.spawn_ranks(2, [], script=script)
+    out, err = capfd.readouterr()
+    assert rc != 0 and out.strip() == ""                     # no result line from a failed job
+    assert "failed" in err
+
+
+def test_spawn_ranks_fails_without_a_result_line(tmp_path, capfd):
+    script = _script(tmp_path, "print('nothing useful')\n")
+    assert bench.spawn_ranks(2, [], script=script) == 1
+    out, _ = capfd.readouterr()
+    assert out.strip() == ""
+
+
+def test_main_becomes_the_launcher_only_without_a_launcher_environment(monkeypatch):
+    calls = []
+    monkeypatch.setattr(bench, "spawn_ranks", lambda gpus, argv, **kw: calls.append((gpus, list(argv))) or 0)
+    monkeypatch.setattr(bench, "_imports", lambda: pytest.fail("the launcher process must not load the GPU stack"))
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert bench.main(["--gpus", "4", "--steps", "20", "--warmup", "5"]) == 0
+    assert calls == [(4, ["--gpus", "4", "--steps", "20", "--warmup", "5"])]
+    # under a launcher the rank count must match --gpus: a mismatch is an error, not a silent n_gpus = 1
+    monkeypatch.setenv("WORLD_SIZE", "3")
+    assert bench.main(["--gpus", "2"]) == 2
+    monkeypatch.delenv("WORLD_SIZE")
+    assert bench.main(["--gpus", "0"]) == 2
+    assert len(calls) == 1
+
+
+def test_gpus_defaults_to_the_launchers_world_size(monkeypatch):
+    seen = {}
+
+    def stop():
+        raise RuntimeError("reached the compute part")
+    monkeypatch.setattr(bench, "_imports", stop)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(RuntimeError, match="compute part"):          # no --gpus: WORLD_SIZE decides, no mismatch error
+        bench.main(["--steps", "1"])
+    monkeypatch.delenv("WORLD_SIZE")
+    with pytest.raises(RuntimeError, match="compute part"):          # neither: one rank, in this process
+        bench.main(["--steps", "1"])
+    assert seen == {}

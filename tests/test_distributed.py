@@ -431,3 +431,270 @@ def test_rccl_world1_library_communicator():
         ret = man.dict()
         mp.spawn(_rccl_world1_worker, args=(1, port, ret), nprocs=1, join=True)
         assert dict(ret) == {0: "ok"}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 3: the library's own exchange (pdlp_iterate on a sharded handle) with 2 and 3 ranks, sharded Ruiz, sharded mixed + Ruiz
+# ---------------------------------------------------------------------------------------------------------------------
+FAKE_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rccl")
+
+
+def _fake_rccl():
+    """path of the test-only librccl stand-in (tests/fake_rccl: ranks sharing one GPU, staging through shared memory), built on
+    first use -- real RCCL refuses two ranks on one device, and this box has one"""
+    import subprocess
+    so, src = os.path.join(FAKE_DIR, "libfake_rccl.so"), os.path.join(FAKE_DIR, "fake_rccl.cpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["bash", os.path.join(FAKE_DIR, "build.sh")])
+    return so
+
+
+def _ordered_comm():
+    """a Comm whose all-reduce adds the ranks' contributions in rank order (as the stand-in library does), so that the
+    torch.distributed loop and the library path see the same bits also with three ranks (gloo's ring adds in another order)"""
+    from torchpdlp_amd.engine import Comm
+
+    class OrderedComm(Comm):
+        def all_reduce_sum(self, t, op=None):
+            if op is not None and op != self.dist.ReduceOp.SUM:
+                return super().all_reduce_sum(t, op)
+            host = t.detach().cpu()
+            parts = [torch.zeros_like(host) for _ in range(self.world)]
+            self.dist.all_gather(parts, host, group=self.group)
+            acc = parts[0].clone()
+            for p in parts[1:]:
+                acc += p
+            t.copy_(acc)
+    return OrderedComm()
+
+
+def _libcomm_worker(rank, world, port, ret, tiled):
+    """every sharded engine twice -- driven by the torch.distributed loop (engine.py) and by the library's own exchange
+    (pdlp_iterate -> iterate_sharded, csrc/pdlp_hip.hip) over the stand-in librccl -- from the same state: same bits"""
+    os.environ["PDLP_TILED"] = "1" if tiled else "0"
+    import torchpdlp_amd as tp
+    from torchpdlp_amd import _native as N
+    from torchpdlp_amd.distributed import gather_solution, shard_engine
+    from torchpdlp_amd.solver import run_pdlp
+    _init(rank, world, port)
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        fake = _fake_rccl() if rank == 0 else None
+        dist.barrier()
+        fake = _fake_rccl()
+        comm = _ordered_comm()
+        if tiled:        # wide enough for several 64K-column panels per rank: the products are split around the exchange
+            lp = gen_lp(330_000, 300_000, 4, seed=12, device=dev, recipe="mixed", dtype=torch.float64)
+        else:            # sizes that do not divide by the world size
+            lp = gen_lp(301, 403, 4, seed=21, recipe="mixed", ineq_frac=0.6, device=dev, dtype=torch.float64)
+        g = torch.Generator().manual_seed(3)
+        x0 = torch.randn(lp.n, generator=g, dtype=torch.float64).to(dev)
+        y0 = torch.randn(lp.m, generator=g, dtype=torch.float64).to(dev)
+        rough = torch.randn(lp.val.numel(), generator=g, dtype=torch.float64).to(dev) * 1e-9       # makes entries that are no float32 numbers
+        configs = [("f32", torch.float32, None, False), ("f64", torch.float64, None, False), ("mixed", torch.float32, torch.float64, False)]
+        if not tiled:
+            configs.append(("mixed+exact", torch.float64, torch.float64, True))
+        for name, mat_dt, vec_dt, exact in configs:
+            vd = vec_dt or mat_dt
+            val = lp.val + rough if exact else lp.val
+            K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, val.to(mat_dt))
+            vecs = [t.to(vd) for t in (lp.c, lp.q, lp.l, lp.u)]
+
+            def mk():
+                if exact:
+                    return shard_engine(K.to(dtype=torch.float32), *vecs, lp.m_ineq, comm, vec_dtype=vd, exact=K)
+                return shard_engine(K, *vecs, lp.m_ineq, comm, vec_dtype=vec_dt)
+            eA, eB = mk(), mk()
+            assert eB.enable_library_comm(rccl_path=fake, timeout=60.0), (name, eB.lib_comm_log)
+            assert eB.lib_comm and not eA.lib_comm and any("bit-identical" in s for s in eB.lib_comm_log)
+            if tiled:
+                assert all(t is not None for t in eB.tiles) and eB.split_info(0)["local_groups"] >= 1
+            for adaptive in (True, False):
+                outs = []
+                for e in (eA, eB):
+                    e.set_iterate(e.part.pad_cols(x0.to(vd))[e.cols[0]:e.cols[1]], e.part.pad_rows(y0.to(vd))[e.rows[0]:e.rows[1]])
+                    e.set_step(0.02, 1.1, 1.0, 0)
+                    e.iterate(9, adaptive)
+                    e.iterate(4, adaptive)
+                    x, y = e.get_iterate(N.CUR)
+                    outs.append((x.clone(), y.clone(), e.scalars()["eta"], e.kkt(N.CUR, 1.0)["kkt"]))
+                (xa, ya, ea, ka), (xb, yb, eb, kb) = outs
+                assert torch.equal(xa, xb) and torch.equal(ya, yb), (name, adaptive)
+                assert ea == eb and ka == kb, (name, adaptive, ea, eb, ka, kb)
+                assert bool(torch.isfinite(xa).all()) and float(xa.abs().sum()) > 0
+            if not tiled and name in ("f32", "mixed"):
+                # a whole restarted solve: identical restart decisions, counters and solution on both paths
+                sols = []
+                for e in (eA, eB):
+                    b0 = e.part.pad_cols(torch.randn(lp.n, generator=torch.Generator().manual_seed(9)).to(dev))
+                    tr = dict(kkt=[], omega=[], restarts=[])
+                    x, obj, k, n, j, st, _ = run_pdlp(e, tol=1e-4 if name == "f32" else 1e-7, verbose=False, primal_update=True,
+                                                      adaptive=True, b0=b0, trace=tr, max_kkt=300_000)
+                    sols.append((gather_solution(e, x, lp.n).cpu(), obj, k, n, j, st, tr["restarts"]))
+                assert sols[0][1:] == sols[1][1:] and torch.equal(sols[0][0], sols[1][0]), name
+                assert sols[0][5] == "Solved" and abs(sols[0][1] - lp.opt_obj) <= 2e-3 * (1 + abs(lp.opt_obj))
+            del eA, eB
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,tiled", [(2, False), (3, False), (2, True), (3, True)])
+def test_library_exchange_equals_the_torch_distributed_loop(world, tiled):
+    """iterate_sharded had never run with more than one rank.  2 and 3 ranks share the card; the library's
+    communicator is the test-only stand-in (tests/fake_rccl).  f32, f64, mixed/delta (+ a separate exact matrix), adaptive and
+    fixed step, plain and split (tiled) products."""
+    port = _free_port()
+    with mp.Manager() as man:
+        ret = man.dict()
+        mp.spawn(_libcomm_worker, args=(world, port, ret, tiled), nprocs=world, join=True)
+        assert dict(ret) == {r: "ok" for r in range(world)}
+
+
+def _ruiz_worker(rank, world, port, ret):
+    """sharded Ruiz: the scaled shards are the shards of the scaled matrix, bit for bit; then configs[4]'s combination
+    (Ruiz + adaptive + primal weight, mixed precision) sharded over the ranks with no full copy anywhere"""
+    import torchpdlp_amd as tp
+    from torchpdlp_amd import _native as N
+    from torchpdlp_amd.distributed import engine_from_shard, gather_solution, gen_lp_shard_arrays, shard_arrays
+    from torchpdlp_amd.precondition import ruiz_precondition_shard
+    from torchpdlp_amd.solver import run_pdlp
+    _init(rank, world, port)
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        comm = tp.Comm()
+        gz = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ruiz.npz"))
+        cases = sorted({"/".join(k.split("/")[:3]) for k in gz.files})
+        t = lambda v: torch.tensor(np.asarray(v), dtype=torch.float32, device=dev)
+        for case in cases:        # the reference's own inputs (dense K), incl. an all-zero row / column and the Q3 early exit
+            r = {k.split("/")[-1]: gz[k] for k in gz.files if k.startswith(case + "/")}
+            iters = int(case.rsplit("it", 1)[1])
+            K = tp.CsrPair.from_any(t(r["K"]), device=dev)
+            m_ineq = K.m // 2
+            full = tp.ruiz_precondition(t(r["c"]), K, t(r["q"]), t(r["l"]), t(r["u"]), device=dev, max_iter=iters)
+            Ks, c_s, q_s, l_s, u_s, (D_col, D_row, *_), _ = full
+            for balance in ("rows", "nnz"):
+                sh = shard_arrays(K, t(r["c"]), t(r["q"]), t(r["l"]), t(r["u"]), m_ineq, rank, world, balance=balance)
+                part = sh["part"]
+                got = ruiz_precondition_shard({k: v for k, v in sh.items() if k != "part"}, comm, max_iter=iters)
+                want = shard_arrays(Ks, c_s, q_s, l_s, u_s, m_ineq, rank, world, d_col=D_col, d_row=D_row, balance=balance, part=part)
+                for key in ("K_rows", "KT_rows"):
+                    for a, b in zip(got[key], want[key]):
+                        assert torch.equal(a, b.to(a.dtype)), (case, balance, key)
+                for key in ("c", "q", "l", "u", "d_col", "d_row"):
+                    assert torch.equal(got[key], want[key]), (case, balance, key)
+        # a generated instance that exists only as shards: (a) against the single-process Ruiz of the whole instance
+        n, m, k = 70_001, 131_075, 6
+        sh = gen_lp_shard_arrays(n, m, k, 9, comm, dev, torch.float64)
+        got = ruiz_precondition_shard({kk: v for kk, v in sh.items() if kk not in ("part", "nnz_local")}, comm)
+        lp = gen_lp(n, m, k, seed=9, device=dev, dtype=torch.float64)
+        K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
+        Ks, c_s, q_s, l_s, u_s, (D_col, D_row, *_), _ = tp.ruiz_precondition(lp.c, K, lp.q, lp.l, lp.u, device=dev)
+        want = shard_arrays(Ks, c_s, q_s, l_s, u_s, lp.m_ineq, rank, world, d_col=D_col, d_row=D_row, balance="rows")
+        for key in ("K_rows", "KT_rows"):
+            assert torch.equal(got[key][2], want[key][2]) and torch.equal(got[key][1], want[key][1]), key
+        for key in ("c", "q", "l", "u", "d_col", "d_row"):
+            assert torch.equal(got[key], want[key]), key
+        assert got["ruiz_sweeps"] >= 1
+        # (b) the whole configs[4] combination on it, mixed precision: the scaled entries are no float32 numbers, so every rank
+        # iterates on the float32 rounding and refreshes the anchors from its float64 blocks
+        eng = engine_from_shard(sh, comm, precision="mixed", precondition=True)
+        assert eng.mixed and eng.delta and eng.exact is not None and eng.d_col is not None
+        TOL = 1e-5       # (every iteration of this rehearsal crosses the host three times over gloo: 1e-8 is left to the small LPs below)
+        x, obj, kk, nn, jj, status, _ = run_pdlp(eng, tol=TOL, verbose=False, precondition=True, primal_update=True, adaptive=True,
+                                                 seed=2, max_kkt=2_000_000, time_limit=600)
+        assert status == "Solved", status
+        xs = gather_solution(eng, x, n)                       # scaled iterate (quirk Q4); un-scale with the gathered D_col
+        dfull = torch.empty(eng.n, dtype=torch.float64, device=dev)
+        dfull[eng.cols[0]:eng.cols[1]] = eng.d_col
+        comm.all_gather(dfull)
+        xu = xs * eng.part.unpad_cols(dfull)
+        # float64 check of the ORIGINAL problem, independent of the engine: feasibility and objective
+        rows = torch.repeat_interleave(torch.arange(lp.m, device=dev), (lp.rowptr[1:] - lp.rowptr[:-1]).long())
+        kx = torch.zeros(lp.m, dtype=torch.float64, device=dev).index_add_(0, rows, lp.val * xu[lp.colidx.long()])
+        res = kx - lp.q
+        res[:lp.m_ineq].clamp_(max=0)
+        assert float(res.norm()) <= 1.01 * TOL * (1 + float(lp.q.norm()))
+        assert float((xu - lp.l).clamp(max=0).abs().max()) <= 1e-9 and float((lp.u - xu).clamp(max=0).abs().max()) <= 1e-9
+        assert abs(float((lp.c * xu).sum()) - obj) <= 1e-9 * (1 + abs(obj))
+        if rank == 0:      # the same solve on one rank reaches the same optimum
+            e1 = engine_from_shard(dict(shard_arrays(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq, 0, 1, balance="rows")), None,
+                                   precision="mixed", precondition=True)
+            _, obj1, *_rest, st1, _ = run_pdlp(e1, tol=TOL, verbose=False, precondition=True, primal_update=True, adaptive=True,
+                                               seed=2, max_kkt=2_000_000, time_limit=600)
+            assert st1 == "Solved" and abs(obj1 - obj) <= 20 * TOL * (1 + abs(obj))
+        # the user-facing entry points with the combination ADVICE r2 reported as refused: mixed + precondition, sharded, incl. a
+        # matrix on which Ruiz is the identity (+-1 entries: the scaled matrix IS float32-valued, no separate exact matrix)
+        lp2 = gen_lp(301, 403, 4, seed=21, recipe="mixed", ineq_frac=0.6, device=dev, dtype=torch.float64)
+        K2 = tp.CsrPair(lp2.m, lp2.n, lp2.rowptr, lp2.colidx, lp2.val)
+        res = tp.solve_lp((lp2.c, K2, lp2.q, lp2.m_ineq, lp2.l, lp2.u), device=dev, tol=1e-8, precondition=True, primal_weight_update=True,
+                          adaptive_stepsize=True, seed=1, comm=True, precision="mixed", max_kkt=2_000_000)
+        assert res.status == "Solved" and abs(res.objective - lp2.opt_obj) <= 1e-6 * (1 + abs(lp2.opt_obj))
+        afiro = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mps", "afiro.mps")
+        res = tp.solve_lp(afiro, device=dev, tol=1e-8, precondition=True, primal_weight_update=True, adaptive_stepsize=True, seed=3,
+                          comm=True, precision="mixed", max_kkt=2_000_000)
+        assert res.status == "Solved" and abs(res.objective - (-464.7531428571)) <= 1e-5
+        Kpm = tp.CsrPair(lp2.m, lp2.n, lp2.rowptr, lp2.colidx, torch.sign(lp2.val) + (lp2.val == 0))
+        res = tp.solve_lp((lp2.c, Kpm, lp2.q, lp2.m_ineq, lp2.l, lp2.u), device=dev, tol=1e-6, precondition=True, primal_weight_update=True,
+                          adaptive_stepsize=True, seed=1, comm=True, precision="mixed", max_kkt=400_000, time_limit=120)
+        assert not res.status.startswith("Solver failed") and res.x.shape == (lp2.n, 1)
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_ruiz_and_config4_mixed_precision(world):
+    port = _free_port()
+    with mp.Manager() as man:
+        ret = man.dict()
+        mp.spawn(_ruiz_worker, args=(world, port, ret), nprocs=world, join=True)
+        assert dict(ret) == {r: "ok" for r in range(world)}
+
+
+def _infeas_delta_worker(rank, world, port, ret):
+    """the detector on a sharded mixed/delta engine multiplied K' by stale blocks of y (the delta iterations exchange
+    only differences).  Now y is gathered first: same diagnostics as one rank."""
+    import torchpdlp_amd as tp
+    from torchpdlp_amd.distributed import shard_engine
+    _init(rank, world, port)
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        lp = gen_lp(301, 403, 4, seed=21, recipe="mixed", ineq_frac=0.6, device=dev, dtype=torch.float64)
+        K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val.float())
+        comm = tp.Comm()
+
+        def run(e):
+            e.set_iterate(torch.zeros(e.nl, dtype=torch.float64, device=dev), torch.zeros(e.ml, dtype=torch.float64, device=dev))
+            e.set_step(0.05, 1.0, 1.0, 0)
+            e.infeas_reset()
+            out = []
+            for tol in (1e-2, 1e-2, 1e3):
+                e.iterate(2, True)
+                out.append(e.detect_infeasibility(tol, diagnostics=True))
+            return out
+        es = shard_engine(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq, comm, vec_dtype=torch.float64)
+        assert es.delta and es.comm is not None
+        got = run(es)
+        if rank == 0:
+            e1 = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq, vec_dtype=torch.float64)
+            for (s, d), (s1, d1) in zip(got, run(e1)):
+                assert s == s1
+                np.testing.assert_allclose(d, d1, rtol=1e-9, atol=1e-9)
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_delta_mode_infeasibility_detector_sees_the_whole_y():
+    port = _free_port()
+    with mp.Manager() as man:
+        ret = man.dict()
+        mp.spawn(_infeas_delta_worker, args=(2, port, ret), nprocs=2, join=True)
+        assert dict(ret) == {0: "ok", 1: "ok"}

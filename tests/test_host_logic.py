@@ -223,7 +223,8 @@ def test_bench_command_line_contract(monkeypatch):
     bench = importlib.import_module("bench")
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse()
-    assert (a.gpus, a.n, a.nnz_per_row, a.mode, a.dtype) == (1, 10_000_000, 100, "adaptive", "f32")
+    assert (a.gpus, a.n, a.nnz_per_row, a.mode, a.dtype) == (None, 10_000_000, 100, "adaptive", "f32")   # (None: the launcher's WORLD_SIZE, else 1)
+    assert not a.ruiz and a.lib_comm == "auto"
     assert a.solve_tol == 1e-4 and a.solve_limit > 0
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
     a = bench.parse()

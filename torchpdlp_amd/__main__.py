@@ -64,18 +64,42 @@ def main(argv=None) -> int:
         if not dist.is_initialized():
             dist.init_process_group(os.environ.get("PDLP_DIST_BACKEND", "nccl"))
         comm = True
+    else:
+        dist = None
     if rank == 0:
         print(f"PyTorch is using ROCm/CUDA device: {torch.cuda.get_device_name(torch.cuda.current_device())}"
               + (f" x {world} ranks" if world > 1 else ""))
     files = sorted(f for f in os.listdir(args.instance_path) if f.endswith(".mps"))       # main.py:83
     results = []
+
+    def failed_ranks(failed: bool) -> int:
+        """how many ranks failed on this instance (collective: every rank calls it once per instance, success or not)"""
+        if world == 1:
+            return int(failed)
+        host = dist.get_backend() == "gloo"
+        t = torch.tensor([int(failed)], dtype=torch.int32, device="cpu" if host else torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(t)
+        return int(t)
+
+    def write_results():
+        os.makedirs(args.output_path, exist_ok=True)
+        if results:
+            out = os.path.join(args.output_path, "solver_results.csv")
+            with open(out, "w", newline="") as f:
+                w = csv.DictWriter(f, fieldnames=COLUMNS)
+                w.writeheader()
+                w.writerows(results)
+            print(f"Results saved to CSV instead: {out}")
+        else:
+            print("No results to save.")
     for name in files:
         path = os.path.join(args.instance_path, name)
         print(f"\nProcessing {path}...")
         dtype = torch.float32 if args.dtype == "fp32" else torch.float64
         try:                            # main.py:88-103: a file that does not load gets its own kind of row
-            problem = mps_to_standard_form(path, device=torch.device("cuda", torch.cuda.current_device()), verbose=args.verbose,
-                                           compat=not args.standard_mps, dtype=dtype)
+            # (sharded runs parse on the host and put only this rank's blocks on its GPU: api._solve_lp_sharded)
+            problem = mps_to_standard_form(path, device="cpu" if world > 1 else torch.device("cuda", torch.cuda.current_device()),
+                                           verbose=args.verbose, compat=not args.standard_mps, dtype=dtype)
         except Exception as e:
             print(f"Failed to load MPS file: {path}. Error: {e}")
             msg = str(e)
@@ -91,26 +115,26 @@ def main(argv=None) -> int:
             print(f"Solver uses {r.time:.4f} seconds.\nStatus: {r.status}")
             results.append({"File": name, "Objective": f"{r.objective:.6f}", "Iterations (k)": r.iterations, "Restarts (n)": r.restarts,
                             "KKT Passes (j)": r.kkt_passes, "Time (s)": f"{r.time:.4f}", "Status": r.status})      # main.py:142-150
+            bad = failed_ranks(False)
         except Exception as e:          # the reference records the failure and goes on (main.py:152-162)
             print(f"Solver failed for {name}. Error: {e}")
             results.append(_fail_row(name, "Solver failed", e))
-            if world > 1:
-                # a rank-local failure (out of memory on one shard, ...) leaves the other ranks inside a collective: do not go
-                # on to the next instance out of step -- leave, so that the job fails loudly instead of hanging
-                print(f"rank {rank}: leaving the sharded run after a failure in {name}", file=sys.stderr, flush=True)
-                os._exit(3)
+            bad = failed_ranks(True)
+        if 0 < bad < world:
+            # only some ranks failed (out of memory on one shard, ...): the ranks are out of step and the next instance would hang
+            # in its first collective.  Rank 0 saves what there is -- the rows of the instances solved so far -- and the job ends
+            # non-zero.  (A failure every rank hits alike -- an unsupported option combination, a bad instance -- is a row like
+            # any other: the loop goes on, as the reference's does.)
+            print(f"rank {rank}: {bad} of {world} ranks failed on {name}; leaving the sharded run", file=sys.stderr, flush=True)
+            if rank == 0:
+                if results[-1]["Status"] == "Solved" or not results[-1]["Status"].startswith("Solver failed"):
+                    results[-1] = _fail_row(name, "Solver failed", RuntimeError(f"{bad} of {world} ranks failed"))
+                write_results()
+            sys.stdout.flush()
+            os._exit(3)
     if rank != 0:
         return 0
-    os.makedirs(args.output_path, exist_ok=True)
-    if results:
-        out = os.path.join(args.output_path, "solver_results.csv")
-        with open(out, "w", newline="") as f:
-            w = csv.DictWriter(f, fieldnames=COLUMNS)
-            w.writeheader()
-            w.writerows(results)
-        print(f"Results saved to CSV instead: {out}")
-    else:
-        print("No results to save.")
+    write_results()
     return 0
 
 

@@ -45,14 +45,21 @@ def solve_lp(problem: Union[str, os.PathLike, tuple], device=None, tol: float = 
     fast way there: float32 matrix entries under float64 vectors, iterations on the float32 kernels (``pdlp_algorithm``).
     ``infeasibility_detect`` runs the reference's detector
     (enhancements.py:80-161) after every iteration, with its behaviour as it is.  Under ``torchrun`` (one process per GPU, process
-    group initialised) pass ``comm=True``: every rank reads the same problem, keeps its row blocks of K and K', and
-    all return the full solution.
+    group initialised) pass ``comm=True``: every rank reads the same problem ON THE HOST, puts only its row blocks of K and K'
+    on its GPU (the Ruiz sweeps run on the shards), and all return the full solution -- no GPU ever holds the whole LP.
     """
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     if precision is not None:
         if precision != "mixed":
             raise ValueError(f"unknown precision {precision!r}")
         dtype = torch.float64
+    if comm is not None and not fishnet:
+        from .engine import Comm
+        cm = Comm() if comm is True else comm
+        if cm.world > 1:
+            return _solve_lp_sharded(problem, cm, device, tol, precondition, primal_weight_update, adaptive_stepsize, max_kkt, time_limit,
+                                     verbose, restart_period, dtype, seed, compat, x_init, y_init, trace, infeasibility_detect,
+                                     infeas_tol, precision)
     if isinstance(problem, (str, os.PathLike)):
         c, K, q, m_ineq, l, u = mps_to_standard_form(os.fspath(problem), device=device, verbose=verbose, compat=compat, dtype=dtype)
     else:
@@ -77,3 +84,39 @@ def solve_lp(problem: Union[str, os.PathLike, tuple], device=None, tol: float = 
     if precondition:        # the reference returns the scaled iterate (quirk Q4); solve_lp un-scales: x = D_col x_s (pdhg.py:161)
         x = data_precond[0].view(-1, 1).to(x.dtype) * x
     return LPResult(x, obj, k, n, j, status, total)
+
+
+def _solve_lp_sharded(problem, comm, device, tol, precondition, primal_weight_update, adaptive_stepsize, max_kkt, time_limit, verbose,
+                      restart_period, dtype, seed, compat, x_init, y_init, trace, infeasibility_detect, infeas_tol, precision) -> LPResult:
+    """``solve_lp`` over the ranks of ``comm``: the problem is read (or taken) on the host by every rank, cut into blocks balanced
+    by non-zeros, and only this rank's blocks go to its GPU; Ruiz (enhancements.py:4-71) runs on the shards, the solve is
+    ``run_pdlp`` on the sharded engine (pdhg.py:7-181), and every rank returns the full un-scaled solution."""
+    from .distributed import engine_from_shard, gather_solution, shard_arrays
+    from .solver import run_pdlp
+    from .sparse import as_vec
+    if isinstance(problem, (str, os.PathLike)):
+        c, K, q, m_ineq, l, u = mps_to_standard_form(os.fspath(problem), device="cpu", verbose=verbose and comm.rank == 0, compat=compat,
+                                                     dtype=dtype)
+    else:
+        c, K, q, m_ineq, l, u = problem
+        K = CsrPair.from_any(K, dtype=dtype)             # (where the caller has it: host or device)
+    n, m = K.n, K.m
+    sh = shard_arrays(K, c, q, l, u, m_ineq, comm.rank, comm.world, vec_dtype=dtype, balance="nnz")
+    part = sh["part"]
+    one = lambda t: t.to(device) if isinstance(t, torch.Tensor) else t
+    mv = lambda v: tuple(one(t) for t in v) if isinstance(v, tuple) else one(v)
+    sh = {k: (v if k == "part" else mv(v)) for k, v in sh.items() if v is not None}
+    del K
+    eng = engine_from_shard(sh, comm, precision=precision, precondition=precondition)
+    time_used = float(getattr(eng, "ruiz_seconds", 0.0))
+    vdt = eng.dtype
+    if x_init is not None and y_init is not None:          # full vectors in (of the scaled problem when preconditioned, like the
+        x_init = part.pad_cols(as_vec(x_init, n, device, vdt))[eng.cols[0]:eng.cols[1]]    # one-GPU path and main.py:114-130);
+        y_init = part.pad_rows(as_vec(y_init, m, device, vdt))[eng.rows[0]:eng.rows[1]]    # this rank's blocks of the padded layout on
+    x, obj, k, nr, j, status, total = run_pdlp(eng, max_kkt, tol, verbose and comm.rank == 0, restart_period, precondition,
+                                               primal_weight_update, adaptive_stepsize, time_limit, time_used, x_init, y_init,
+                                               seed=0 if seed is None else seed, trace=trace,
+                                               infeasibility_detect=infeasibility_detect, infeas_tol=infeas_tol)
+    if precondition:
+        x = x * eng.d_col
+    return LPResult(gather_solution(eng, x, n).view(-1, 1), obj, k, nr, j, status, total)

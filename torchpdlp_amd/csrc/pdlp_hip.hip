@@ -412,7 +412,8 @@ template <typename T> int primal_half_t(pdlp_handle h, int adaptive)
     const int src = (h->no_kty_reuse || h->graph_ok || h->sKT.pending) ? -1 : (h->kty_cur >= 0 ? h->kty_cur : (h->cand_valid[0] ? 0 : -1));
     // K'y of the previous iterate's y joins the running sum unless this is the first half-step after a reset (that y is the
     // restart point) or the restart check's flush has already added it
-    T* ksum = (h->since_reset > 0 && !h->kty_tail_done && !h->sums_broken && !h->no_running) ? (T*)h->kty_sum : nullptr;
+    // (not under graph replay: a captured launch would freeze this decision)
+    T* ksum = (h->since_reset > 0 && !h->kty_tail_done && !h->sums_broken && !h->no_running && !h->graph_ok) ? (T*)h->kty_sum : nullptr;
     if (adaptive) {
         PrimalEpi<T, true> e{xloc<T>(h, h->ix_cur), xloc<T>(h, h->ix_prev), (T*)h->xbar + h->p.col0, (const T*)h->p.c,
                              (const T*)h->p.l, (const T*)h->p.u, (T*)h->x_sum, sc, ksum};
@@ -447,7 +448,7 @@ template <typename T> int dual_half_t(pdlp_handle h, int adaptive)
 {
     int rc;
     if (!h->kx_valid && (rc = refresh_kx_t<T>(h)) != PDLP_OK) return rc;      // K x of the current x: carried along from here on
-    T* ksum = (h->sums_broken || h->no_running) ? nullptr : (T*)h->kx_sum;
+    T* ksum = (h->sums_broken || h->no_running || h->graph_ok) ? nullptr : (T*)h->kx_sum;
     if (adaptive) {
         DualEpi<T, true> e{yloc<T>(h, h->ix_cur), yloc<T>(h, h->ix_prev), (const T*)h->p.q, (T*)h->y_sum, (T*)h->kxb[0],
                            h->sc, h->ineq_end, ksum};
@@ -730,7 +731,7 @@ int delta_kkt_local(pdlp_handle h, int which, int unscaled)
 
 template <typename T> int flush_t(pdlp_handle h, int adaptive)
 {
-    const bool running = !h->delta && !h->sums_broken && !h->no_running && h->since_reset > 0;
+    const bool running = !h->delta && !h->sums_broken && !h->no_running && !h->graph_ok && h->since_reset > 0;
     if (adaptive) {
         // the weight of the current iterate became known only after its step-size rule: add it now
         hipLaunchKernelGGL(k_flush<T>, dim3(grid_for(h->nl)), dim3(BLOCK), 0, h->stream, h->nl, (T*)h->x_sum,
@@ -1021,7 +1022,7 @@ int read_last_rowptr(const int32_t* rp, int64_t rows, int64_t* nnz, hipStream_t 
 // ================================================================================================
 extern "C" {
 
-int pdlp_abi_version(void) { return 10; }  // 10: pdlp_set_anchors; 9: pdlp_attach_sorted; 8: running products, pdlp_flush_average(h, adaptive); 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
+int pdlp_abi_version(void) { return 11; }  // 11: pdlp_comm_load; 10: pdlp_set_anchors; 9: pdlp_attach_sorted; 8: running products, pdlp_flush_average(h, adaptive); 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
 
 const char* pdlp_strerror(int code)
 {
@@ -1404,6 +1405,7 @@ pdlp_solver::IterGraph* pair_graph(pdlp_handle h, int adaptive)
     if (hipStreamBeginCapture(h->gstream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
         h->graph_ok = false;
+        h->sums_broken = true;        // (the running sums were not kept while replay was on: no running average before the next restart)
         return nullptr;
     }
     h->stream = h->gstream;
@@ -1419,6 +1421,7 @@ pdlp_solver::IterGraph* pair_graph(pdlp_handle h, int adaptive)
         if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
         h->graph_ok = false;
+        h->sums_broken = true;        // (the running sums were not kept while replay was on: no running average before the next restart)
         return nullptr;
     }
     (void)hipGraphDestroy(graph);
@@ -1476,6 +1479,8 @@ int iterate_sharded(pdlp_handle h, int iters, int adaptive)
 
 }  // namespace
 
+int pdlp_comm_load(const char* rccl_path) { return rccl_load(rccl_path); }
+
 int pdlp_comm_unique_id(const char* rccl_path, void* id128)
 {
     if (!id128) return PDLP_ERR_INVALID;
@@ -1532,7 +1537,7 @@ int pdlp_iterate(pdlp_handle h, int iters, int adaptive)
     if (h->nl != h->p.n || h->ml != h->p.m) return PDLP_ERR_STATE;   // sharded without a communicator: the caller does the exchange
     int rc, left = iters;
     if (h->graph_ok && left >= 5) {
-        if (adaptive && !h->kx_valid) {          // the first adaptive iteration after a reset also refreshes the K x cache
+        if (!h->kx_valid) {          // the first iteration after a reset also refreshes the K x cache: never inside a captured pair
             if ((rc = iterate_direct(h, 1, adaptive)) != PDLP_OK) return rc;
             --left;
         }
@@ -1544,7 +1549,6 @@ int pdlp_iterate(pdlp_handle h, int iters, int adaptive)
             HIP_TRY(hipEventRecord(h->ev_out, h->gstream));
             HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_out, 0));
             h->cand_valid[0] = h->cand_valid[1] = false;     // (what two direct iterations leave behind)
-            if (!adaptive) h->kx_valid = false;
             if (adaptive) { h->last_gridA = grid_of(h->sKT, h->nl); h->last_gridB = grid_of(h->sK, h->ml); }
         }
     }

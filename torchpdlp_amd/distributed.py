@@ -169,16 +169,57 @@ def shard_arrays(K: CsrPair, c, q, l, u, m_ineq: int, rank: int, world: int, d_c
 
 
 def shard_engine(K: CsrPair, c, q, l, u, m_ineq: int, comm: Optional[Comm], d_col=None, d_row=None, vec_dtype=None,
-                 balance: str = "nnz") -> PdlpEngine:
+                 balance: str = "nnz", exact: Optional[CsrPair] = None) -> PdlpEngine:
     """Engine for this rank's block of a problem every rank holds in full (small/medium problems and tests; the benchmark
     and anything that does not fit one GPU use ``gen_lp_shard`` / per-rank loading instead).  ``eng.part`` maps between
-    the original and the padded index space."""
+    the original and the padded index space.  ``exact``: the float64 matrix of which ``K`` is the float32 rounding (mixed
+    precision on a matrix that is not float32-valued); it is cut into the same blocks."""
     if comm is None or comm.world == 1:
-        return PdlpEngine.from_full(K, c, q, l, u, m_ineq, d_col=d_col, d_row=d_row, vec_dtype=vec_dtype)
+        return PdlpEngine.from_full(K, c, q, l, u, m_ineq, d_col=d_col, d_row=d_row, vec_dtype=vec_dtype, exact=exact)
     args = shard_arrays(K, c, q, l, u, m_ineq, comm.rank, comm.world, d_col, d_row, vec_dtype, balance)
     part = args.pop("part")
-    eng = PdlpEngine(comm=comm, vec_dtype=vec_dtype, **args)
+    ex = None
+    if exact is not None:
+        ea = shard_arrays(exact, c, q, l, u, m_ineq, comm.rank, comm.world, None, None, vec_dtype, balance, part=part)
+        ex = (ea["K_rows"], ea["KT_rows"])
+    eng = PdlpEngine(comm=comm, vec_dtype=vec_dtype, exact=ex, **args)
     eng.part = part
+    return eng
+
+
+def engine_from_shard(shard: dict, comm: Optional[Comm], precision: Optional[str] = None, precondition: bool = False,
+                      ruiz_iters: int = 20, ruiz_eps: float = 1e-6) -> PdlpEngine:
+    """Engine over one rank's shard of a problem that exists only as shards (``gen_lp_shard_arrays``, ``shard_arrays``): no
+    rank ever holds the whole LP, also not for the preconditioning -- ``precondition=True`` runs the sharded Ruiz sweeps
+    (``precondition.ruiz_precondition_shard``: row norms are rank local, one all-gather of the factors per half-sweep) and the
+    engine then carries ``d_col`` / ``d_row`` for the un-scaled termination test (pdhg.py:157-161).
+    ``precision="mixed"``: float64 vectors over float32 matrix values (pass the shard in float64).  If some rank's scaled
+    entries are not float32 numbers, every rank iterates on the float32 rounding and evaluates the anchors of delta mode with
+    its float64 blocks (``exact``)."""
+    from .engine import values_are_float32
+    shard = dict(shard)
+    extra = {k: shard.pop(k) for k in ("part", "nnz_local", "ruiz_seconds", "ruiz_sweeps") if k in shard}
+    if precondition:
+        from .precondition import ruiz_precondition_shard
+        shard = ruiz_precondition_shard(shard, comm, ruiz_iters, ruiz_eps)
+        extra["ruiz_seconds"], extra["ruiz_sweeps"] = shard.pop("ruiz_seconds"), shard.pop("ruiz_sweeps")
+    vec_dtype, exact = None, None
+    if precision is not None:
+        if precision != "mixed":
+            raise ValueError(f"unknown precision {precision!r}")
+        K_rows, KT_rows = shard["K_rows"], shard["KT_rows"]
+        dev = K_rows[2].device
+        f32ok = torch.tensor([int(values_are_float32(K_rows[2]) and values_are_float32(KT_rows[2]))], dtype=torch.int32, device=dev)
+        if comm is not None and comm.world > 1:
+            comm.all_reduce_min(f32ok)                   # every rank must build the same kind of engine
+        if not int(f32ok):
+            exact = ((K_rows[0], K_rows[1], K_rows[2].double()), (KT_rows[0], KT_rows[1], KT_rows[2].double()))
+        shard["K_rows"] = (K_rows[0], K_rows[1], K_rows[2].float())
+        shard["KT_rows"] = (KT_rows[0], KT_rows[1], KT_rows[2].float())
+        vec_dtype = torch.float64
+    eng = PdlpEngine(comm=comm, vec_dtype=vec_dtype, exact=exact, **shard)
+    for k, v in extra.items():
+        setattr(eng, k, v)
     return eng
 
 
@@ -281,11 +322,16 @@ def gen_lp_shard_arrays(n: int, m: int, nnz_per_row: int, seed: int, comm: Comm,
 
 
 def gen_lp_shard(n: int, m: int, nnz_per_row: int, seed: int, comm: Comm, device, dtype=torch.float32, ineq_frac: float = 0.8,
-                 vec_dtype=None) -> PdlpEngine:
-    """engine over ``gen_lp_shard_arrays``: no rank ever holds the whole instance"""
+                 vec_dtype=None, precision: Optional[str] = None, precondition: bool = False) -> PdlpEngine:
+    """engine over ``gen_lp_shard_arrays``: no rank ever holds the whole instance (``precision`` / ``precondition``:
+    ``engine_from_shard``; mixed precision generates the shard in float64)"""
+    if precision is not None:
+        dtype, vec_dtype = torch.float64, None
     args = gen_lp_shard_arrays(n, m, nnz_per_row, seed, comm, device, dtype, ineq_frac, vec_dtype)
-    part = args.pop("part")
-    nnz_local = args.pop("nnz_local")
-    eng = PdlpEngine(comm=comm, vec_dtype=vec_dtype, **args)
-    eng.part, eng.nnz_local = part, nnz_local
-    return eng
+    if precision is None and not precondition:
+        part = args.pop("part")
+        nnz_local = args.pop("nnz_local")
+        eng = PdlpEngine(comm=comm, vec_dtype=vec_dtype, **args)
+        eng.part, eng.nnz_local = part, nnz_local
+        return eng
+    return engine_from_shard(args, comm, precision, precondition)

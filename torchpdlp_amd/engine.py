@@ -46,13 +46,20 @@ class Comm:
         else:
             self.dist.all_gather_into_tensor(full, mine, group=self.group)
 
-    def all_reduce_sum(self, t: torch.Tensor):
+    def all_reduce_sum(self, t: torch.Tensor, op=None):
+        op = self.dist.ReduceOp.SUM if op is None else op
         if self.backend == "gloo" and t.is_cuda:
             host = t.cpu()
-            self.dist.all_reduce(host, group=self.group)
+            self.dist.all_reduce(host, op=op, group=self.group)
             t.copy_(host)
         else:
-            self.dist.all_reduce(t, group=self.group)
+            self.dist.all_reduce(t, op=op, group=self.group)
+
+    def all_reduce_max(self, t: torch.Tensor):
+        self.all_reduce_sum(t, self.dist.ReduceOp.MAX)
+
+    def all_reduce_min(self, t: torch.Tensor):
+        self.all_reduce_sum(t, self.dist.ReduceOp.MIN)
 
 
 class PdlpEngine:
@@ -70,7 +77,8 @@ class PdlpEngine:
         else on) then runs the iterations on the float32 kernels over float32 difference vectors added to float64 anchor
         products (``pdlp_set_delta`` in include/pdlp_hip.h).  ``exact`` = ``(K_rows, KT_rows)`` in float64: the TRUE matrix when the
         float32 one handed in as ``K_rows`` / ``KT_rows`` is only its rounding (any float64 matrix, a Ruiz-scaled one): the anchors
-        of delta mode are then evaluated with it (a second, float64 CSR handle; ``pdlp_set_anchors``), single GPU only."""
+        of delta mode are then evaluated with it (a second, float64 CSR handle over the same row blocks; ``pdlp_set_anchors``).
+        A scaled matrix whose entries ARE float32 numbers (Ruiz on a +-1 matrix is the identity) needs no ``exact``."""
         self.lib = N.load()
         rows = (0, m) if rows is None else rows
         cols = (0, n) if cols is None else cols
@@ -90,11 +98,8 @@ class PdlpEngine:
         self.mixed = self.dtype != self.mat_dtype
         if self.mixed and (self.mat_dtype, self.dtype) != (torch.float32, torch.float64):
             raise ValueError("mixed precision means float32 matrix values under float64 vectors")
-        if self.mixed and (d_col is not None or d_row is not None) and exact is None:
-            raise ValueError("mixed precision needs the matrix entries to be float32 numbers; a Ruiz-scaled matrix is not: "
-                             "pass the float64 matrix as `exact` (pdlp_algorithm(precision='mixed') does)")
-        if exact is not None and (comm is not None and comm.world > 1):
-            raise ValueError("mixed precision with a separate exact matrix runs on one GPU")
+        if exact is not None and not self.mixed:
+            raise ValueError("`exact` (the float64 matrix behind a float32 rounding) belongs to mixed precision")
         i32 = lambda t: t.to(device=self.device, dtype=torch.int32).contiguous()
         fv = lambda t, ln: None if t is None else as_vec(t, ln, self.device, self.dtype)
         # keep every tensor the library points into alive
@@ -122,7 +127,7 @@ class PdlpEngine:
         self._want_tiles = bool(tiles)
         self.exact = None
         if exact is not None:          # the true float64 matrix, CSR kernels only: two products per restart
-            self.exact = PdlpEngine(m, n, m_ineq, exact[0], exact[1], c, q, l, u, rows=rows, cols=cols, tiles=False)
+            self.exact = PdlpEngine(m, n, m_ineq, exact[0], exact[1], c, q, l, u, rows=rows, cols=cols, comm=comm, tiles=False)
         self._sorted = [None, None]
         self._mv_work = {}
         self.tiles = [None, None]
@@ -131,8 +136,10 @@ class PdlpEngine:
         self.delta = False
         if self.mixed and (delta if delta is not None else os.environ.get("PDLP_DELTA", "1") != "0"):
             self.set_delta(True)
-        self.lib_comm = False
-        if self.comm is not None and self.comm.backend == "nccl" and os.environ.get("PDLP_LIB_COMM", "1") != "0":
+        # the exchange inside the library (one C call per restart period) is opt-in: PDLP_LIB_COMM=1 here, or
+        # enable_library_comm() by the caller (bench.py does); the default is the torch.distributed loop of iterate()
+        self.lib_comm, self.lib_comm_log = False, []
+        if self.comm is not None and self.comm.backend == "nccl" and tiles and os.environ.get("PDLP_LIB_COMM", "0") == "1":
             self.enable_library_comm()
 
     # ---- panel-tiled matrix copies (fast path for wide gathered vectors) -------------------------------
@@ -263,54 +270,108 @@ class PdlpEngine:
             pass
         return None
 
-    def enable_library_comm(self, dist=None, group=None) -> bool:
+    def enable_library_comm(self, dist=None, group=None, rccl_path: Optional[str] = None, timeout: float = 120.0,
+                            cross_check: bool = True) -> bool:
         """Give the handle its own RCCL communicator (``pdlp_comm_init``): ``iterate`` then is ONE library call per restart
         period -- half-steps, all-gathers and the step-size all-reduce enqueued back to back on the stream -- instead of six
-        ctypes calls and three torch collectives per iteration.  The id travels over the existing process group; a round
-        trip of both collectives is checked against known values on every rank, and unless ALL ranks pass, all of them
-        stay on the torch.distributed path.  Returns whether the library path is on."""
+        ctypes calls and three torch collectives per iteration.  Every step is agreed on by ALL ranks over the existing process
+        group before the next one: (1) the library loads (``pdlp_comm_load``, rank local), (2) the id travels from rank 0,
+        (3) ``pdlp_comm_init`` in a helper thread with ``timeout`` seconds -- a hang becomes a fallback --, (4) a round trip of
+        both collectives against known values, (5) ``cross_check``: two adaptive iterations from one synthetic state through the
+        torch.distributed loop and through the library path must agree bit for bit.  Any failure anywhere leaves all ranks on
+        the torch.distributed loop.  Call before the iterate is set (the cross-check overwrites it and resets it to zero).
+        ``rccl_path``: the library to dlopen (default: the librccl this process has mapped -- PyTorch's).  ``self.lib_comm_log``
+        records what happened.  Returns whether the library path is on."""
+        import threading
         if dist is None:
             if self.comm is None:
                 return False
             dist, group = self.comm.dist, self.comm.group
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        path = self._loaded_rccl()
+        host_coll = dist.get_backend(group) == "gloo"           # rehearsal on a shared card: collectives through host tensors
+        log = self.lib_comm_log = []
+
+        def agree(ok: int) -> int:                               # MIN over the ranks
+            flag = torch.tensor([int(ok)], dtype=torch.int32, device="cpu" if host_coll else self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            return int(flag)
+
+        path = rccl_path if rccl_path is not None else self._loaded_rccl()
         cpath = None if path is None else path.encode()
+        if not agree(self.lib.pdlp_comm_load(cpath) == 0):
+            log.append("load failed on some rank")
+            return False
         idbuf = (C.c_char * 128)()
         ok = 1
         if rank == 0 and self.lib.pdlp_comm_unique_id(cpath, idbuf) != 0:
             ok = 0
-        t = torch.tensor(list(idbuf.raw) + [ok], dtype=torch.uint8, device=self.device)
+        t = torch.tensor(list(idbuf.raw) + [ok], dtype=torch.uint8, device="cpu" if host_coll else self.device)
         dist.broadcast(t, 0, group=group)
         raw = bytes(t.cpu().tolist())
-        ok = raw[128]
+        if not raw[128]:
+            log.append("unique id failed")
+            return False
         C.memmove(idbuf, raw[:128], 128)
-        if ok and self.lib.pdlp_comm_init(self.h, cpath, idbuf, rank, world) != 0:
+        res = {}
+
+        def init():
+            res["rc"] = self.lib.pdlp_comm_init(self.h, cpath, idbuf, rank, world)
+        th = threading.Thread(target=init, daemon=True)
+        th.start()
+        th.join(timeout)
+        if not agree((not th.is_alive()) and res.get("rc") == 0):
+            log.append(f"init failed or timed out (this rank: alive={th.is_alive()}, rc={res.get('rc')})")
+            return False
+        # round trip: all-gather of a full-length vector and the 8-double all-reduce (rank-local errors are caught, so that
+        # every rank reaches the agreement below)
+        ok = 1
+        try:
+            dx, red = self.buffer(N.BUF_DX), self.buffer(N.BUF_RED)
+            dx.zero_()
+            dx[self.cols[0]:self.cols[1]] = rank + 1
+            red.fill_(rank + 1)
+            N.check(self.lib.pdlp_comm_all_gather(self.h, N.BUF_DX), "pdlp_comm_all_gather")
+            N.check(self.lib.pdlp_comm_all_reduce_red(self.h), "pdlp_comm_all_reduce_red")
+            self.stream.synchronize()
+            want = torch.arange(1, world + 1, device=self.device, dtype=dx.dtype).repeat_interleave(self.nl)
+            ok = int(torch.equal(dx, want) and bool((red == world * (world + 1) / 2).all()))
+            dx.zero_()
+            red.zero_()
+        except N.PdlpError:
             ok = 0
-        # every rank must have a communicator before any of them enters a collective on it (a rank that failed to initialise
-        # would leave the others waiting in the round trip below)
-        flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-        ok = int(flag)
-        if ok:          # round trip: all-gather of a full-length float vector and the 8-double all-reduce
+        if not agree(ok):
+            log.append("round trip wrong")
+            return False
+        if cross_check:
             try:
-                dx, red = self.buffer(N.BUF_DX), self.buffer(N.BUF_RED)
-                dx.zero_()
-                dx[self.cols[0]:self.cols[1]] = rank + 1
-                red.fill_(rank + 1)
-                N.check(self.lib.pdlp_comm_all_gather(self.h, N.BUF_DX), "pdlp_comm_all_gather")
-                N.check(self.lib.pdlp_comm_all_reduce_red(self.h), "pdlp_comm_all_reduce_red")
-                self.stream.synchronize()
-                want = torch.arange(1, world + 1, device=self.device, dtype=dx.dtype).repeat_interleave(self.nl)
-                ok = int(torch.equal(dx, want) and bool((red == world * (world + 1) / 2).all()))
-                dx.zero_()
-                red.zero_()
+                same = int(self._cross_check_paths())
             except N.PdlpError:
-                ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-        self.lib_comm = bool(int(flag))
-        return self.lib_comm
+                same = 0
+            if not agree(same):
+                self.lib_comm = False
+                log.append("cross-check against the torch.distributed loop differs")
+                return False
+            log.append("cross-check: 2 adaptive iterations bit-identical on both paths")
+        self.lib_comm = True
+        return True
+
+    def _cross_check_paths(self, iters: int = 2, eta: float = 1e-2) -> bool:
+        """`iters` adaptive iterations from x = y = 0 through the torch.distributed loop and through the library's own
+        exchange: the same bits on this rank?  Leaves the engine at x = y = 0, eta = 0 (a fresh handle's state)."""
+        zeros = lambda ln: torch.zeros(ln, dtype=self.dtype, device=self.device)
+        out = []
+        for lib in (False, True):
+            self.lib_comm = lib
+            self.set_iterate(zeros(self.nl), zeros(self.ml))
+            self.set_step(eta, 1.0, 1.0, 0)
+            self.iterate(iters, True)
+            x, y = self.get_iterate(N.CUR)
+            out.append((x, y, self.scalars()["eta"]))
+        self.lib_comm = False
+        self.set_iterate(zeros(self.nl), zeros(self.ml))
+        self.set_step(0.0, 1.0, 1.0, 0)
+        (x0, y0, e0), (x1, y1, e1) = out
+        return bool(torch.equal(x0, x1) and torch.equal(y0, y1) and e0 == e1 and bool(torch.isfinite(x0).all()))
 
     def set_delta(self, on: bool):
         """delta mode of a mixed-precision engine (include/pdlp_hip.h, pdlp_set_delta)"""
@@ -325,7 +386,12 @@ class PdlpEngine:
     def refresh_products(self):
         """recompute K x and K'y of the current iterate exactly (float64 accumulation): the anchors of delta mode"""
         if self.exact is not None:     # the handle's matrix is the float32 rounding of the true one: anchors from the true one
-            x, y = self.get_iterate(N.CUR)
+            if self.comm is not None:  # (sharded: the products need the complete iterate)
+                self._gather(N.BUF_X_CUR)
+                self._gather(N.BUF_Y_CUR)
+                x, y = self.buffer(N.BUF_X_CUR), self.buffer(N.BUF_Y_CUR)
+            else:
+                x, y = self.get_iterate(N.CUR)
             kx, kty = self.exact.spmv(x, False), self.exact.spmv(y, True)
             N.check(self.lib.pdlp_set_anchors(self.h, kx.data_ptr(), kty.data_ptr()), "pdlp_set_anchors")
             return
@@ -500,6 +566,8 @@ class PdlpEngine:
         if self.comm is not None:
             self.comm.all_gather(self.buffer(N.BUF_DX))
             self.comm.all_gather(self.buffer(N.BUF_DY))
+            if self.delta:      # lambda = proj(c - K'y) multiplies the COMPLETE y; delta iterations exchange only the differences
+                self._gather(N.BUF_Y_CUR)
         N.check(self.lib.pdlp_infeas_local(self.h, float(tol)), "pdlp_infeas_local")
         if self.comm is not None:
             self.comm.all_reduce_sum(self.buffer(N.BUF_RED))

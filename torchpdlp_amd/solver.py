@@ -304,8 +304,8 @@ def pdlp_algorithm(K, m_ineq, c, q, l, u, device=None, max_kkt=100_000, tol=1e-4
     resolution (the reference is float32 only) on matrices whose entries are float32 numbers (checked); 8 instead of 12 bytes
     per non-zero, and the iterations run on the float32 kernels over difference vectors (delta mode, include/pdlp_hip.h).
     ``c, q, l, u`` are taken in float64.  A matrix that is NOT float32-valued (any float64 ``K``, a Ruiz-scaled one with
-    ``precondition=True``) works too, on one GPU: the iterations then run on its float32 rounding and the anchors of delta mode and the
-    termination test are evaluated with the true float64 matrix after every restart.
+    ``precondition=True``) works too, sharded included: the iterations then run on its float32 rounding and the anchors of delta
+    mode and the termination test are evaluated with the true float64 matrix after every restart.
 
     ``comm`` (a ``Comm``, or ``True`` for the default ``torch.distributed`` group): every rank calls with the SAME
     full problem and the same ``seed``/``b0``; each keeps its row blocks of K and K', the iterations exchange
@@ -324,9 +324,8 @@ def pdlp_algorithm(K, m_ineq, c, q, l, u, device=None, max_kkt=100_000, tol=1e-4
         from .engine import values_are_float32
         if not (values_are_float32(Kp.val) and values_are_float32(Kp.t_val)):
             # any float64 matrix (e.g. a Ruiz-scaled one): the iterations run on its float32 ROUNDING (they only multiply
-            # difference vectors), the anchors and the termination test use the true matrix (engine.py, `exact`)
-            if comm is not None and (comm is True or comm.world > 1):
-                raise ValueError("precision='mixed' on a matrix that is not float32-valued runs on one GPU")
+            # difference vectors), the anchors and the termination test use the true matrix (engine.py, `exact`; sharded: every
+            # rank holds the same full matrix here, so all ranks take this branch together)
             exact_K = Kp
         Kp = Kp.to(dtype=torch.float32)
         dtype = vec_dtype = torch.float64
@@ -341,7 +340,7 @@ def pdlp_algorithm(K, m_ineq, c, q, l, u, device=None, max_kkt=100_000, tol=1e-4
         from .distributed import gather_solution, shard_engine
         if seed is None and b0 is None and sigma is None:
             seed = 0                                   # the ranks must draw the same power-iteration start
-        eng = shard_engine(Kp, c, q, l, u, m_ineq, comm, d_col=d_col, d_row=d_row, vec_dtype=vec_dtype)    # blocks balanced by non-zeros
+        eng = shard_engine(Kp, c, q, l, u, m_ineq, comm, d_col=d_col, d_row=d_row, vec_dtype=vec_dtype, exact=exact_K)    # blocks balanced by non-zeros
         if x_init is not None and y_init is not None:  # full vectors in, this rank's blocks of the padded layout on
             xi = eng.part.pad_cols(as_vec(x_init, Kp.n, device, dtype))
             yi = eng.part.pad_rows(as_vec(y_init, Kp.m, device, dtype))
