@@ -20,6 +20,7 @@ Groups:
   G9 afiro.npz           Netlib afiro: util.mps_to_standard_form + pdlp_algorithm (+ ruiz_precondition)
   G10 infeasibility.npz  detect_infeasibility (enhancements.py:80-161) and pdlp_algorithm(infeasibility_detect=True)
   G11 fishnet.npz        spectral_cast / sample_points / fishnet / init_PDHG_vars / get_best_pts (spectral_casting.py:5-293)
+  G13 forced_trace_more.npz  the same for the other three seeded LPs (round 3)
   G12 forced_trace.npz   pdlp_algorithm(adaptive=True): state at the start and end of every 40-iteration block
 """
 import contextlib
@@ -496,7 +497,7 @@ def g11_fishnet(cases):
     np.savez_compressed(os.path.join(HERE, "fishnet.npz"), **out)
 
 
-def g12_forced_trace(cases):
+def g12_forced_trace(cases, spec=(("mixed_400x300", (0, 3, 9, 20)), ("box_200x150", (0, 2, 7, 12))), fname="forced_trace.npz"):
     """pdlp_algorithm(adaptive=True, primal_update=True): the state (x, y, eta, omega, k) going into EVERY step of a few
     40-iteration blocks of the reference's own run and what the step returned.  A test feeds each recorded state to one
     step and compares with the recorded successor, so the whole real trajectory (accepted and rejected steps, the phases
@@ -504,7 +505,7 @@ def g12_forced_trace(cases):
     the amplification of rounding differences that makes whole blocks incomparable: with the step sizes forced to the
     reference's, a 1e-5 difference still grows 3x per step while eta sits above eta_bar (measured on box_200x150)."""
     out = {}
-    for name, blocks in (("mixed_400x300", (0, 3, 9, 20)), ("box_200x150", (0, 2, 7, 12))):
+    for name, blocks in spec:
         lp = cases[name]
         K = csr_to_dense(lp)
         calls = []
@@ -539,11 +540,18 @@ def g12_forced_trace(cases):
                                              x_out=st(5), y_out=st(6), eta_used=sc(7), eta_hat=sc(8)))
         rej = sum(1 for b in blocks for c_ in calls[40 * b:40 * b + 40] if c_[7] != c_[2])
         print(f"G12 {name}: {len(calls)} adaptive calls, blocks {blocks} recorded step by step ({rej} rejected steps), {status} k={k}")
-    np.savez_compressed(os.path.join(HERE, "forced_trace.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+
+
+def g13_forced_trace_more(cases):
+    """round 3: the same recording for the other three seeded LPs (all-equality, all-inequality, the afiro-sized one), so that
+    every step of real adaptive runs is pinned on all five LP cases (own file: forced_trace.npz stays byte for byte)"""
+    g12_forced_trace(cases, (("mixed_27x32", (0, 1, 4)), ("mixed_300x400_alleq", (0, 2, 6)), ("mixed_200x260_allineq", (0, 2, 6))),
+                     "forced_trace_more.npz")
 
 
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"}
+    which = set(sys.argv[1:]) or {"g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"}
     cases = lp_cases()
     if "g1" in which: g1_step_fixed(cases)
     if "g2" in which: g2_step_adaptive(cases)
@@ -557,5 +565,6 @@ if __name__ == "__main__":
     if "g10" in which: g10_infeasibility(cases)
     if "g11" in which: g11_fishnet(cases)
     if "g12" in which: g12_forced_trace(cases)
+    if "g13" in which: g13_forced_trace_more(cases)
     print("golden fixtures written to", HERE)
 

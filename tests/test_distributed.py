@@ -599,20 +599,26 @@ def _ruiz_worker(rank, world, port, ret):
         for key in ("c", "q", "l", "u", "d_col", "d_row"):
             assert torch.equal(got[key], want[key]), key
         assert got["ruiz_sweeps"] >= 1
-        # (b) the whole configs[4] combination on it, mixed precision: the scaled entries are no float32 numbers, so every rank
-        # iterates on the float32 rounding and refreshes the anchors from its float64 blocks
+        del got, want, Ks, K, lp, sh
+        # (b) the whole configs[4] combination -- Ruiz + adaptive + primal weight, mixed precision, 1e-8 -- on an instance that exists
+        # only as shards (small: every iteration of this rehearsal crosses the host three times over gloo).  The scaled entries are
+        # no float32 numbers, so every rank iterates on the float32 rounding and refreshes the anchors from its float64 blocks.
+        n, m, k = 3000, 5000, 6
+        sh = gen_lp_shard_arrays(n, m, k, 9, comm, dev, torch.float64)
         eng = engine_from_shard(sh, comm, precision="mixed", precondition=True)
-        assert eng.mixed and eng.delta and eng.exact is not None and eng.d_col is not None
-        TOL = 1e-5       # (every iteration of this rehearsal crosses the host three times over gloo: 1e-8 is left to the small LPs below)
+        assert eng.mixed and eng.delta and eng.exact is not None and eng.d_col is not None and eng.ruiz_sweeps >= 1
+        TOL = 1e-8
         x, obj, kk, nn, jj, status, _ = run_pdlp(eng, tol=TOL, verbose=False, precondition=True, primal_update=True, adaptive=True,
-                                                 seed=2, max_kkt=2_000_000, time_limit=600)
+                                                 seed=2, max_kkt=2_000_000, time_limit=240)
         assert status == "Solved", status
         xs = gather_solution(eng, x, n)                       # scaled iterate (quirk Q4); un-scale with the gathered D_col
         dfull = torch.empty(eng.n, dtype=torch.float64, device=dev)
         dfull[eng.cols[0]:eng.cols[1]] = eng.d_col
         comm.all_gather(dfull)
         xu = xs * eng.part.unpad_cols(dfull)
-        # float64 check of the ORIGINAL problem, independent of the engine: feasibility and objective
+        # float64 check against the ORIGINAL problem, independent of the engine: feasibility and objective
+        lp = gen_lp(n, m, k, seed=9, device=dev, dtype=torch.float64)
+        K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
         rows = torch.repeat_interleave(torch.arange(lp.m, device=dev), (lp.rowptr[1:] - lp.rowptr[:-1]).long())
         kx = torch.zeros(lp.m, dtype=torch.float64, device=dev).index_add_(0, rows, lp.val * xu[lp.colidx.long()])
         res = kx - lp.q
@@ -624,7 +630,7 @@ def _ruiz_worker(rank, world, port, ret):
             e1 = engine_from_shard(dict(shard_arrays(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq, 0, 1, balance="rows")), None,
                                    precision="mixed", precondition=True)
             _, obj1, *_rest, st1, _ = run_pdlp(e1, tol=TOL, verbose=False, precondition=True, primal_update=True, adaptive=True,
-                                               seed=2, max_kkt=2_000_000, time_limit=600)
+                                               seed=2, max_kkt=2_000_000, time_limit=240)
             assert st1 == "Solved" and abs(obj1 - obj) <= 20 * TOL * (1 + abs(obj))
         # the user-facing entry points with the combination ADVICE r2 reported as refused: mixed + precondition, sharded, incl. a
         # matrix on which Ruiz is the identity (+-1 entries: the scaled matrix IS float32-valued, no separate exact matrix)
@@ -636,11 +642,12 @@ def _ruiz_worker(rank, world, port, ret):
         afiro = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mps", "afiro.mps")
         res = tp.solve_lp(afiro, device=dev, tol=1e-8, precondition=True, primal_weight_update=True, adaptive_stepsize=True, seed=3,
                           comm=True, precision="mixed", max_kkt=2_000_000)
-        assert res.status == "Solved" and abs(res.objective - (-464.7531428571)) <= 1e-5
+        assert res.status == "Solved" and abs(res.objective - (-464.7531428571)) <= 1e-7 * (1 + 2 * 464.7531428571), \
+            (res.status, res.objective, res.iterations)      # (the tests allow 1e-8 (1 + |p| + |d|) of gap, signed, plus the residuals' share)
         Kpm = tp.CsrPair(lp2.m, lp2.n, lp2.rowptr, lp2.colidx, torch.sign(lp2.val) + (lp2.val == 0))
         res = tp.solve_lp((lp2.c, Kpm, lp2.q, lp2.m_ineq, lp2.l, lp2.u), device=dev, tol=1e-6, precondition=True, primal_weight_update=True,
-                          adaptive_stepsize=True, seed=1, comm=True, precision="mixed", max_kkt=400_000, time_limit=120)
-        assert not res.status.startswith("Solver failed") and res.x.shape == (lp2.n, 1)
+                          adaptive_stepsize=True, seed=1, comm=True, precision="mixed", max_kkt=3_000, time_limit=120)
+        assert res.status in ("Solved", "Unsolved (KKT passes limit exceeded)") and res.x.shape == (lp2.n, 1)   # (it used to raise)
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()
@@ -685,7 +692,7 @@ def _infeas_delta_worker(rank, world, port, ret):
             e1 = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq, vec_dtype=torch.float64)
             for (s, d), (s1, d1) in zip(got, run(e1)):
                 assert s == s1
-                np.testing.assert_allclose(d, d1, rtol=1e-9, atol=1e-9)
+                np.testing.assert_allclose(d, d1, rtol=2e-5, atol=1e-5)      # (float32 difference products: summation order; stale y is O(1) off)
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()

@@ -316,13 +316,17 @@ def test_power_iteration(golden, name, iters):
     np.testing.assert_allclose(float(tp.spectral_norm_estimate_torch(K, iters, b0=dev(r["b0"]))), float(r["sigma"]), rtol=5e-5)
 
 
-@pytest.mark.parametrize("name", ["mixed_400x300", "box_200x150"])
+FORCED = {"mixed_400x300": "forced_trace.npz", "box_200x150": "forced_trace.npz", "mixed_27x32": "forced_trace_more.npz",
+          "mixed_300x400_alleq": "forced_trace_more.npz", "mixed_200x260_allineq": "forced_trace_more.npz"}
+
+
+@pytest.mark.parametrize("name", sorted(FORCED))
 def test_forced_trace_adaptive_steps(golden, name):
     """Every step of recorded 40-iteration blocks of the reference's pdlp_algorithm(adaptive=True, primal_update=True)
     (tests/golden/forced_trace.npz), each taken from the reference's own state before it: accepted and rejected steps
     (quirk Q1), step sizes beyond eta_bar, iterates produced by restarts to the average.  Whole blocks cannot be compared:
     with eta above eta_bar the iteration expands rounding differences 3x per step (gen_golden.g12_forced_trace)."""
-    g = golden("forced_trace.npz")
+    g = golden(FORCED[name])
     a, K, o, eng = golden_lp(g, name)
     blocks = [int(b) for b in a["blocks"]]
     assert len(blocks) >= 3
@@ -343,7 +347,7 @@ def test_forced_trace_adaptive_steps(golden, name):
                 assert bool(s["accepted"]) == acc_ref, (b, i)
                 np.testing.assert_allclose(s["w_pending"], r["eta_used"][i], rtol=2e-3)
                 np.testing.assert_allclose(s["eta"], r["eta_hat"][i], rtol=2e-3)
-    assert rejected >= 1
+    assert rejected >= 1 or name == "mixed_300x400_alleq"        # (the reference's run on that LP rejects no step)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -300,12 +300,16 @@ def test_fishnet_vs_reference(golden, name):
 # ---------------------------------------------------------------------------------------------------
 # every step of blocks of the reference's own adaptive run (tests/golden/forced_trace.npz)
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["mixed_400x300", "box_200x150"])
+FORCED = {"mixed_400x300": "forced_trace.npz", "box_200x150": "forced_trace.npz", "mixed_27x32": "forced_trace_more.npz",
+          "mixed_300x400_alleq": "forced_trace_more.npz", "mixed_200x260_allineq": "forced_trace_more.npz"}
+
+
+@pytest.mark.parametrize("name", sorted(FORCED))
 def test_forced_trace_adaptive_steps(golden, name):
     """Each step of recorded 40-iteration blocks of pdlp_algorithm(adaptive=True, primal_update=True), taken from the
     reference's own state before that step: accepted and rejected steps (quirk Q1), eta beyond eta_bar, iterates that
     restarts to the average produced.  (Whole blocks cannot be compared: see gen_golden.g12_forced_trace.)"""
-    g = golden("forced_trace.npz")
+    g = golden(FORCED[name])
     lp = lp_from(g, name)
     blocks = [int(b) for b in g.group(name)["blocks"]]
     assert len(blocks) >= 3
@@ -326,7 +330,7 @@ def test_forced_trace_adaptive_steps(golden, name):
             rejected += not acc_ref
             if i < 39:       # the loop feeds the step's outputs to the next step unchanged (pdhg.py:80-112)
                 assert np.array_equal(r["x_out"][i], r["x_in"][i + 1]) and r["eta_hat"][i] == r["eta_in"][i + 1]
-    assert rejected >= 1
+    assert rejected >= 1 or name == "mixed_300x400_alleq"        # (the reference's run on that LP rejects no step)
 
 
 # ---------------------------------------------------------------------------------------------------

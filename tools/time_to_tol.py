@@ -54,3 +54,34 @@ x, obj, it, nr, j, status, secs = run_pdlp(eng, max_kkt=max_kkt, tol=tol, verbos
                                            adaptive=True, time_limit=time_limit, seed=0, power_iters=100, trace=trace)
 print(f"RESULT n={n} k={k} tol={tol} ruiz={ruiz} precision={prec}: status={status} obj={obj:.6f} iterations={it} restarts={nr} kkt_passes={j} "
       f"solve_time={secs:.2f}s  ({it/secs:.1f} it/s incl. power iteration and checks)", flush=True)
+
+# ---- independent float64 check of the exit point (at 10M the only evaluator of the 1e-8 claim was the library's own
+# refresh).  Plain torch ops on the ORIGINAL generator arrays (row-regular pattern: k entries per row), no library call:
+# the three tests of check_termination (/root/reference/PDLP/helpers.py:110-128) on the un-scaled iterate.
+from torchpdlp_amd import _native as N
+from torchpdlp_amd.synthetic import _regular_matvec, _regular_rmatvec
+xs, ys = eng.get_iterate(N.CUR)
+xs, ys = xs.double(), ys.double()
+if ruiz:                                     # x = D_col x_s, y = D_row y_s (pdhg.py:161)
+    xs, ys = xs * dcol.view(-1).double(), ys * drow.view(-1).double()
+del eng
+torch.cuda.empty_cache()
+val0 = lp.val if lp.val is not None else K.val            # (the generator's entries; float32 numbers either way)
+c0, q0, l0, u0 = (t.double().view(-1) for t in (lp.c, lp.q, lp.l, lp.u))
+kx = _regular_matvec(lp.colidx, val0, xs, lp.m, k, 1 << 20)
+kty = _regular_rmatvec(lp.colidx, val0, ys, lp.m, lp.n, k, 1 << 20)
+r = kx - q0
+r[:lp.m_ineq].clamp_(max=0)
+g = c0 - kty
+ninf, pinf = torch.isinf(l0) & (l0 < 0), torch.isinf(u0) & (u0 > 0)
+lam = torch.where(ninf & pinf, torch.zeros_like(g), torch.where(ninf, g.clamp(max=0), torch.where(pinf, g.clamp(min=0), g)))
+p_obj = float((c0 * xs).sum())
+d_adj = float((q0 * ys).sum() + (torch.where(ninf, torch.zeros_like(l0), l0) * lam.clamp(min=0)).sum()
+              + (torch.where(pinf, torch.zeros_like(u0), u0) * lam.clamp(max=0)).sum())
+rel = (float(r.norm()) / (1 + float(q0.norm())), float((g - lam).norm()) / (1 + float(c0.norm())),
+       (d_adj - p_obj) / (1 + abs(p_obj) + abs(d_adj)))
+box = max(float((l0 - xs).clamp(min=0).max()), float((xs - u0).clamp(min=0).max()))
+ok = rel[0] <= tol and rel[1] <= tol and rel[2] <= tol
+print(f"INDEPENDENT float64 check (torch ops on the generator's arrays, un-scaled iterate): primal {rel[0]:.3e}  dual {rel[1]:.3e}  "
+      f"gap {rel[2]:+.3e} (signed, Q2)  |gap| {abs(rel[2]):.3e}  bound violation {box:.1e}  objective {p_obj:.6f}  "
+      f"-> {'meets' if ok else 'DOES NOT meet'} tol {tol:g}" + ("" if status == "Solved" else f"  (solver status: {status})"), flush=True)

@@ -173,7 +173,8 @@ class PdlpEngine:
                 continue
             knob = lambda name: int(os.environ[name]) if os.environ.get(name) else None      # tuning experiments
             t = _tiled.build_tiles(rp, ci, va, rows, cols, lw=knob("PDLP_TILE_LW"), rpt=knob("PDLP_TILE_RPT"),
-                                   groups=knob("PDLP_TILE_GROUPS"), max_groups=lim["max_groups"])
+                                   groups=knob("PDLP_TILE_GROUPS"), max_groups=lim["max_groups"],
+                                   kernel_limits=(lim["rpt_max"], lim["cap"]))
             if t is None or t.nblk > lim["max_blocks"]:
                 # clustered (banded, block structured): the CSR kernel, with every row block's items sorted by column
                 if t is None and os.environ.get("PDLP_SORTED", "auto") != "0":

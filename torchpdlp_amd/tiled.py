@@ -235,14 +235,16 @@ def _pack(tile: torch.Tensor, row_in_block: torch.Tensor, sortcol: torch.Tensor,
 
 def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, nrows: int, ncols: int,
                 lw: Optional[int] = None, rpt: Optional[int] = None, cap: Optional[int] = None, max_chunk_nnz: int = 1 << 26,
-                groups: Optional[int] = None, max_groups: int = 8, max_rest: float = 0.30) -> Optional[Tiles]:
+                groups: Optional[int] = None, max_groups: int = 8, max_rest: float = 0.30,
+                kernel_limits: Optional[tuple] = None) -> Optional[Tiles]:
     """CSR (any row lengths, columns sorted or not) -> Tiles, or None when more than ``max_rest`` of the items would not
     fit the tiles proper (a clustered matrix: the CSR kernel is the better one).  Runs on the tensors' device with torch
     sorts (setup cost, done once per matrix)."""
     dev = val.device
     if val.dtype not in (torch.float32, torch.float64):
         return None
-    rpt_max, cap_max = limits(val.dtype)
+    # (rows per thread, items per tile) of the kernel that will read the tiles: the library's build says (pdlp_tile_limits)
+    rpt_max, cap_max = limits(val.dtype) if kernel_limits is None else (int(kernel_limits[0]), int(kernel_limits[1]))
     cap = cap_max if cap is None else cap
     CW = rpt_max // 8
     nnz = int(colidx.numel())
