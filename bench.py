@@ -16,8 +16,8 @@ The LP is resident in HBM before the clock starts.  Default workload = the one t
 on: 10M x 10M, density 1e-5 (100 non-zeros per row), float32 like the reference; it fits one GPU.
 With N > 1 the same instance is sharded (row blocks of K and K'; every rank generates its own shard), so scaling is strong.
 Started as a plain ``python bench.py --gpus N`` (no WORLD_SIZE in the environment) with N > 1, the script starts the N rank
-processes itself (``spawn_ranks``: a child ``python -m torch.distributed.run`` -- before this process has touched a GPU, never an
-exec), relays rank 0's JSON line and exits non-zero if any rank fails.  ``--ruiz`` benchmarks BASELINE configs[4]: the sharded
+processes itself (``spawn_ranks``: N child processes with the launcher's environment -- before this process has touched a GPU,
+never an exec), relays rank 0's JSON line and exits non-zero if any rank fails.  ``--ruiz`` benchmarks BASELINE configs[4]: the sharded
 Ruiz sweeps first (no rank holds the whole LP), then the same timed region on the scaled problem.
 
 Also reports, in the same JSON line:
@@ -42,29 +42,58 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s
 
 
 def spawn_ranks(gpus: int, argv, script: str = None, env: dict = None) -> int:
-    """Start `gpus` rank processes of `script` (this file) under torch.distributed.run as a CHILD process, pass rank 0's JSON
-    line through and return the exit code: 0 only if every rank finished and a line came back.  The caller has not touched
-    the GPU yet, and nothing is exec'ed: the parent stays a plain Python process that waits."""
+    """Start `gpus` rank processes of `script` (this file) as CHILD processes -- one per GPU, each with the launcher environment
+    torch.distributed expects (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR=127.0.0.1, MASTER_PORT) --, pass rank 0's JSON line
+    through and return the exit code: 0 only if every rank finished and a line came back.  The caller has not touched the GPU
+    yet, and nothing is exec'ed: the parent stays a plain Python process that waits.  (Not torch.distributed.run: its argument
+    parser claims abbreviations such as --n or --m of the script's own flags.)  If a rank fails the others are stopped."""
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(gpus)}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
-    e = dict(os.environ if env is None else env)
-    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC (RCCL between processes on this host driver)
-    e.setdefault("OMP_NUM_THREADS", "4")
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=e)
+    base = dict(os.environ if env is None else env)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC (RCCL between processes on this host driver)
+    base.setdefault("OMP_NUM_THREADS", "4")
+    base.update(WORLD_SIZE=str(int(gpus)), LOCAL_WORLD_SIZE=str(int(gpus)), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    cmd = [sys.executable, script or os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r in range(int(gpus)):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")
+        # rank 0's stdout carries the result line; the other ranks' output goes to this process's stderr
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True, env=e))
     lines = []
-    for line in proc.stdout:
-        lines.append(line.rstrip("\n"))
-    rc = proc.wait()
+    import threading
+
+    def pump():
+        for line in procs[0].stdout:
+            lines.append(line.rstrip("\n"))
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    rc, pending = 0, set(range(len(procs)))
+    while pending and rc == 0:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is not None:
+                pending.discard(r)
+                if code != 0:
+                    rc = code if 0 < code < 256 else 1
+                    print(f"bench.py: rank {r} of {gpus} failed (exit code {code})", file=sys.stderr)
+        if pending and rc == 0:
+            time.sleep(0.05)
+    for r in sorted(pending):                                    # a rank failed: stop exactly the processes started here
+        procs[r].terminate()
+    for r in sorted(pending):
+        try:
+            procs[r].wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            procs[r].kill()
+            procs[r].wait()
+    th.join(timeout=10)
     result = [ln for ln in lines if ln.startswith("{") and '"metric"' in ln]
     for ln in lines:
         if ln not in result:
             print(ln, file=sys.stderr)
     if rc != 0:
-        print(f"bench.py: the {gpus}-rank run failed (exit code {rc})", file=sys.stderr)
-        return rc if 0 < rc < 256 else 1
+        return rc
     if not result:
         print("bench.py: the ranks finished without a result line", file=sys.stderr)
         return 1
@@ -81,8 +110,10 @@ def parse(argv=None):
                         "falls back on any difference) or stay on the torch.distributed loop")
     p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=40)
-    p.add_argument("--n", type=int, default=int(os.environ.get("PDLP_BENCH_N", 10_000_000)))
-    p.add_argument("--m", type=int, default=None)
+    # (under `python -m torch.distributed.run ... bench.py` use the long spellings or the environment: that launcher's parser
+    # takes --n and --m for abbreviations of its own options)
+    p.add_argument("--n", "--variables", dest="n", type=int, default=int(os.environ.get("PDLP_BENCH_N", 10_000_000)))
+    p.add_argument("--m", "--constraints", dest="m", type=int, default=None)
     p.add_argument("--nnz-per-row", type=int, default=int(os.environ.get("PDLP_BENCH_NNZ", 100)))
     p.add_argument("--mode", choices=["adaptive", "fixed"], default="adaptive")
     p.add_argument("--dtype", choices=["f32", "f64", "mixed"], default="f32",

@@ -25,13 +25,13 @@ def test_spawn_ranks_relays_rank0_line(tmp_path, capfd):
         if rank == 0:
             print(json.dumps({"metric": "PDHG iterations/sec", "n_gpus": world, "argv": sys.argv[1:]}))
     """)
-    rc = bench.spawn_ranks(2, ["--steps", "7"], script=script)
+    rc = bench.spawn_ranks(2, ["--steps", "7", "--n", "5"], script=script)
     out, err = capfd.readouterr()
     assert rc == 0
     lines = [ln for ln in out.splitlines() if ln.strip()]
     assert len(lines) == 1                                   # exactly the JSON line on stdout; everything else goes to stderr
     got = json.loads(lines[0])
-    assert got["n_gpus"] == 2 and got["argv"] == ["--steps", "7"]
+    assert got["n_gpus"] == 2 and got["argv"] == ["--steps", "7", "--n", "5"]      # (torch.distributed.run would claim --n)
     assert "noise from rank 1" in err
 
 
