@@ -102,7 +102,7 @@ typedef struct pdlp_tiles {
     const uint32_t* idx;        /* [items]                                                                 */
     const void* val;            /* [items] in the problem's precision                                      */
     const int32_t* tile_ptr;    /* [nblk*npanel + 1] item offsets, multiples of 256                        */
-    const uint32_t* cnt;        /* [nblk*npanel*512*(5|3)]                                                 */
+    const uint32_t* cnt;        /* 4-bit counts, 16-byte aligned: [tiles][512][4] words 0..3, then [tiles][cw-4][512]; cw = 5|3                                                 */
     /* the remainder: items the tiles could not hold (more than 15 of a row in one tile, more than 255 of 64 consecutive rows,
      * more than cap in a tile), as segments of <= 512 items of the rows that have any; rem_rows_n = 0: none */
     int32_t rem_rows_n, rem_segs_n;

@@ -38,6 +38,7 @@ better kernel.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Optional
 
@@ -68,7 +69,8 @@ class Tiles:
     idx: torch.Tensor        # int32 [items]  (slot << lw) | local column
     val: torch.Tensor        # float32 / float64 [items]
     tile_ptr: torch.Tensor   # int32 [nblk*npanel + 1], item offsets, multiples of 256
-    cnt: torch.Tensor        # int32 [nblk*npanel*512*cw]: 8*cw nibbles per (tile, thread); cw = 5 (f32) or 3 (f64)
+    cnt: torch.Tensor        # int32: 8*cw nibbles per (tile, thread), cw = 5 (f32) or 3 (f64), laid out for coalesced loads:
+                             #   [tile][thread][4] (words 0..3, zero padded) then [tile][cw - 4][thread] (the other words)
     groups: int = 1          # workgroups sharing a row block (each walks ceil(npanel/groups) panels)
     rpt_max: int = RPT_MAX   # rows per thread the kernel instantiation for this precision supports
     # remainder: segments of <= SEG items of the rows listed in rem_rows
@@ -344,7 +346,7 @@ def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, n
     cat = lambda parts, dt: (parts[0] if len(parts) == 1 else torch.cat(parts)) if parts else torch.zeros(0, dtype=dt, device=dev)
     idx_all, val_all = cat(parts_idx, torch.int32), cat(parts_val, val.dtype)
     del parts_idx, parts_val
-    t = Tiles(lw, rpt, cap, NB, P, nrows, ncols, idx_all, val_all, tile_ptr.to(torch.int32), cat(parts_cnt, torch.int32),
+    t = Tiles(lw, rpt, cap, NB, P, nrows, ncols, idx_all, val_all, tile_ptr.to(torch.int32), _count_layout(cat(parts_cnt, torch.int32), NB * P, CW),
               normalize_groups(groups, P, max(1, int(max_groups))), rpt_max)
     t.stats = dict(nnz=nnz, tiled=nnz - n_over, remainder=0)
     if n_over == 0:
@@ -371,10 +373,33 @@ def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, n
     return t
 
 
+def _count_layout(cnt_tm: torch.Tensor, ntiles: int, CW: int) -> torch.Tensor:
+    """thread-major count words [tile][thread][CW] -> the kernel's layout: [tile][thread][4] (words 0..3 as one 16-byte entry per
+    thread, zero padded when CW < 4), then [tile][CW - 4][thread] (k_tiled_fused, load_counts)"""
+    if os.environ.get("PDLP_CNT_LAYOUT") == "thread":      # A/B timing against a -DPDLP_COUNTS_THREAD_MAJOR build only
+        return cnt_tm
+    c = cnt_tm.view(ntiles, NT, CW)
+    a = torch.zeros(ntiles, NT, 4, dtype=torch.int32, device=c.device)
+    a[:, :, :min(CW, 4)] = c[:, :, :4]
+    if CW <= 4:
+        return a.reshape(-1)
+    return torch.cat([a.reshape(-1), c[:, :, 4:].permute(0, 2, 1).reshape(-1)])
+
+
+def _tile_count_words(t: Tiles, tile: int) -> torch.Tensor:
+    """[512][cw] count words of one tile out of the kernel's layout"""
+    CW, ntiles = t.cw, t.nblk * t.npanel
+    a = t.cnt[tile * NT * 4:(tile + 1) * NT * 4].view(NT, 4)[:, :min(CW, 4)]
+    if CW <= 4:
+        return a
+    off = ntiles * NT * 4 + tile * (CW - 4) * NT
+    return torch.cat([a, t.cnt[off:off + (CW - 4) * NT].view(CW - 4, NT).t()], dim=1)
+
+
 def tile_row_counts(t: Tiles, tile: int) -> torch.Tensor:
     """items of each of the tile's 512*rpt rows (unpacks the nibbles)"""
     CW = t.cw
-    w = t.cnt[tile * NT * CW:(tile + 1) * NT * CW].long() & 0xFFFFFFFF
+    w = _tile_count_words(t, tile).reshape(-1).long() & 0xFFFFFFFF
     shifts = (torch.arange(8, device=w.device) * 4).view(1, 1, 8)
     nib = (w.view(NT, CW, 1) >> shifts) & 15
     per_thread = nib.reshape(NT // 64, 64, t.rpt_max)[:, :, :t.rpt]           # [wave, lane, i]
