@@ -210,6 +210,18 @@ int pdlp_fixed_advance(pdlp_handle h, int iters);
  *   half-steps, the all-gathers of xbar and y (float32 differences in delta mode) overlapped with the local panels' products,
  *   and the 3-double all-reduce of the step-size rule -- on the handle's stream with no host work in between.
  * pdlp_comm_all_gather / pdlp_comm_all_reduce_red: the same collectives for the caller-driven parts (KKT passes, set-up). */
+/* Chunked exchange (round 3).  One all-gather per product exposes the whole transfer minus the 1/P of the product that needs no
+ * foreign entries.  With `chunks` = C > 1 the vector a product gathers travels as C pieces -- piece c = elements
+ * [bounds[c], bounds[c+1]) of EVERY rank's block (pdlp_exchange_plan) -- and the panels a piece completes are multiplied while
+ * the next piece is on the wire: pdlp_*_half_begin, then for c = 0 .. C-2: [piece c has arrived on the handle's stream]
+ * pdlp_half_chunk(h, transpose, c), then [piece C-1 has arrived] pdlp_dual_half / pdlp_primal_half (last piece's panels, the sum of
+ * all partial row sums in fixed order, the epilogue).  transpose = 0: K xbar (pieces of PDLP_BUF_XBAR, or PDLP_BUF_GDX in delta
+ * mode), 1: K'y (PDLP_BUF_Y_CUR / PDLP_BUF_GDY).  Tiled matrices of sharded handles only; otherwise the plan is one piece and
+ * pdlp_half_chunk does nothing.  pdlp_iterate on a handle with a communicator does all of this itself (pieces as grouped
+ * in-place broadcasts on a communication stream of its own). */
+int pdlp_set_exchange_chunks(pdlp_handle h, int chunks /* 1..4 */);
+int pdlp_exchange_plan(pdlp_handle h, int transpose, int32_t* nchunks, int64_t bounds[5]);
+int pdlp_half_chunk(pdlp_handle h, int transpose, int chunk);
 int pdlp_comm_load(const char* rccl_path);
 int pdlp_comm_unique_id(const char* rccl_path, void* id128);
 int pdlp_comm_init(pdlp_handle h, const char* rccl_path, const void* id128, int rank, int nranks);

@@ -1,5 +1,5 @@
 // fake_rccl.cpp -- TEST-ONLY stand-in for librccl, for ranks that SHARE one GPU (real RCCL refuses two ranks on one device).
-// Exports exactly the six nccl* symbols libpdlp_hip.so resolves with dlsym (csrc/pdlp_hip.hip, rccl_load), so that the
+// Exports exactly the nccl* symbols libpdlp_hip.so resolves with dlsym (csrc/pdlp_hip.hip, rccl_load), so that the
 // library's own exchange path -- pdlp_comm_init, pdlp_iterate on a sharded handle -- can run with 2 and 3 ranks on the
 // one-GPU test box.  Transport: a POSIX shared-memory segment named by the "unique id"; a collective drains the stream it
 // is given, stages this rank's block through the segment and meets the other ranks at a barrier (with a timeout: a missing
@@ -153,6 +153,26 @@ ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, n
         out[i] = s;
     }
     if (hipMemcpy(recvbuff, out, count * 8, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+    if (!barrier(c)) return ncclSystemError;
+    return ncclSuccess;
+}
+
+// grouped calls execute one by one, in call order (the same on every rank): nothing to collect
+ncclResult_t ncclGroupStart() { return ncclSuccess; }
+ncclResult_t ncclGroupEnd() { return ncclSuccess; }
+
+ncclResult_t ncclBroadcast(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, int root, ncclComm_t comm,
+                           hipStream_t stream)
+{
+    FakeComm* c = (FakeComm*)comm;
+    const size_t bytes = count * dtype_bytes(datatype);
+    if (!c || dtype_bytes(datatype) == 0 || bytes > c->cap || root < 0 || root >= c->nranks) return ncclInvalidArgument;
+    if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
+    if (c->rank == root && bytes && hipMemcpy(c->data, sendbuff, bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+    if (!barrier(c)) return ncclSystemError;
+    if (c->rank != root && bytes && hipMemcpy(recvbuff, c->data, bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+    if (c->rank == root && recvbuff != sendbuff && bytes &&
+        hipMemcpy(recvbuff, sendbuff, bytes, hipMemcpyDeviceToDevice) != hipSuccess) return ncclUnhandledCudaError;
     if (!barrier(c)) return ncclSystemError;
     return ncclSuccess;
 }

@@ -472,6 +472,8 @@ def _libcomm_worker(rank, world, port, ret, tiled):
     """every sharded engine twice -- driven by the torch.distributed loop (engine.py) and by the library's own exchange
     (pdlp_iterate -> iterate_sharded, csrc/pdlp_hip.hip) over the stand-in librccl -- from the same state: same bits"""
     os.environ["PDLP_TILED"] = "1" if tiled else "0"
+    if tiled:
+        os.environ["PDLP_TILE_LW"] = "13"       # 8K-column panels: ~40 panels, so that a chunked exchange has panels in every piece
     import torchpdlp_amd as tp
     from torchpdlp_amd import _native as N
     from torchpdlp_amd.distributed import gather_solution, shard_engine
@@ -510,19 +512,44 @@ def _libcomm_worker(rank, world, port, ret, tiled):
             assert eB.lib_comm and not eA.lib_comm and any("bit-identical" in s for s in eB.lib_comm_log)
             if tiled:
                 assert all(t is not None for t in eB.tiles) and eB.split_info(0)["local_groups"] >= 1
-            for adaptive in (True, False):
-                outs = []
+            whole = {}
+            for chunks in ((1, 2, 3) if tiled else (1,)):
+                # chunked exchange (tiled products only): the gathered vector travels in `chunks` pieces and the panels a piece
+                # completes are multiplied while the next piece is on the wire -- again the same bits on both drivers, and the
+                # same numbers as the one-piece exchange up to the grouping of the partial row sums
+                if chunks > 1:
+                    for e in (eA, eB):
+                        e.set_exchange_chunks(chunks)
+                        for tr in (0, 1):
+                            plan = e.exchange_plan(tr)
+                            blk = e.ml if tr else e.nl
+                            assert len(plan) == chunks and plan[0][0] == 0 and plan[-1][1] == blk, (plan, blk)
+                            assert all(plan[c][1] == plan[c + 1][0] and plan[c][0] % 64 == 0 for c in range(chunks - 1))
+                            info = e.split_info(tr)
+                            assert info["local_groups"] >= 1 and info["other_groups"] >= chunks, info
+                for adaptive in (True, False):
+                    outs = []
+                    for e in (eA, eB):
+                        e.set_iterate(e.part.pad_cols(x0.to(vd))[e.cols[0]:e.cols[1]], e.part.pad_rows(y0.to(vd))[e.rows[0]:e.rows[1]])
+                        e.set_step(0.02, 1.1, 1.0, 0)
+                        e.iterate(9, adaptive)
+                        e.iterate(4, adaptive)
+                        x, y = e.get_iterate(N.CUR)
+                        outs.append((x.clone(), y.clone(), e.scalars()["eta"], e.kkt(N.CUR, 1.0)["kkt"]))
+                    (xa, ya, ea, ka), (xb, yb, eb, kb) = outs
+                    assert torch.equal(xa, xb) and torch.equal(ya, yb), (name, adaptive, chunks)
+                    assert ea == eb and ka == kb, (name, adaptive, chunks, ea, eb, ka, kb)
+                    assert bool(torch.isfinite(xa).all()) and float(xa.abs().sum()) > 0
+                    if chunks == 1:
+                        whole[adaptive] = (xa, ya, ka)
+                    else:
+                        tol = 2e-4 if vd == torch.float32 else 1e-9
+                        np.testing.assert_allclose(xa.cpu().numpy(), whole[adaptive][0].cpu().numpy(), rtol=tol, atol=tol)
+                        np.testing.assert_allclose(ya.cpu().numpy(), whole[adaptive][1].cpu().numpy(), rtol=tol, atol=tol)
+                        np.testing.assert_allclose(ka, whole[adaptive][2], rtol=10 * tol)
+            if tiled:
                 for e in (eA, eB):
-                    e.set_iterate(e.part.pad_cols(x0.to(vd))[e.cols[0]:e.cols[1]], e.part.pad_rows(y0.to(vd))[e.rows[0]:e.rows[1]])
-                    e.set_step(0.02, 1.1, 1.0, 0)
-                    e.iterate(9, adaptive)
-                    e.iterate(4, adaptive)
-                    x, y = e.get_iterate(N.CUR)
-                    outs.append((x.clone(), y.clone(), e.scalars()["eta"], e.kkt(N.CUR, 1.0)["kkt"]))
-                (xa, ya, ea, ka), (xb, yb, eb, kb) = outs
-                assert torch.equal(xa, xb) and torch.equal(ya, yb), (name, adaptive)
-                assert ea == eb and ka == kb, (name, adaptive, ea, eb, ka, kb)
-                assert bool(torch.isfinite(xa).all()) and float(xa.abs().sum()) > 0
+                    e.set_exchange_chunks(1)
             if not tiled and name in ("f32", "mixed"):
                 # a whole restarted solve: identical restart decisions, counters and solution on both paths
                 sols = []

@@ -2,7 +2,9 @@
 """One rank's shard of the bench problem on ONE GPU: how long a dual half-step takes when its product is split into
 "local panels first (side stream), the others after the all-gather" versus unsplit, with a spin kernel of the
 all-gather's duration standing in for the collective.  Used to choose the panel-group counts of the split.
-env: WORLD (8), AG_MS (0.1), SLOTS ("a,b" overrides the library's choice via PDLP_SPLIT_SLOTS), N, K"""
+env: WORLD (8), AG_MS (0.1), SLOTS ("a,b" overrides the library's choice via PDLP_SPLIT_SLOTS), N, K,
+CHUNKS ("1,2,4": also time the chunked exchange -- the stand-in then runs as that many spin kernels on a second stream, each a
+1/chunks of AG_MS, and the panels a piece completes are launched when its spin kernel is done)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["PDLP_TILED"] = "1"
@@ -62,6 +64,40 @@ def run(split, reps=20):
     return ts[0], ts[len(ts) // 2]
 
 
+def run_chunked(chunks, reps=20):
+    """the exchange as `chunks` spin kernels on a communication stream; products of the completed pieces on the main stream"""
+    N_.check(lib.pdlp_set_exchange_chunks(h, chunks))
+    main, comm = torch.cuda.current_stream(), torch.cuda.Stream()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        ready = torch.cuda.Event(); ready.record(main)
+        N_.check(lib.pdlp_dual_half_begin(h, 0))
+        evs = []
+        with torch.cuda.stream(comm):
+            comm.wait_event(ready)
+            for c in range(chunks):
+                torch.cuda._sleep(spin // chunks)
+                e = torch.cuda.Event(); e.record(comm); evs.append(e)
+        for c in range(chunks - 1):
+            main.wait_event(evs[c])
+            N_.check(lib.pdlp_half_chunk(h, 0, c))
+        main.wait_event(evs[-1])
+        N_.check(lib.pdlp_dual_half(h, 0))
+        b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ts.sort()
+    N_.check(lib.pdlp_set_exchange_chunks(h, 1))
+    return ts[0], ts[len(ts) // 2]
+
+
 run(False, 3); run(True, 3)
 u, s = run(False), run(True)
 print(f"WORLD={W} shard {m}x{n}  all-gather stand-in {ag_ms} ms:  unsplit min {u[0]:.3f} med {u[1]:.3f} ms | split min {s[0]:.3f} med {s[1]:.3f} ms", flush=True)
+for ch in [int(v) for v in os.environ.get("CHUNKS", "").split(",") if v]:
+    if ch > 1:
+        run_chunked(ch, 3)
+        c = run_chunked(ch)
+        N_.check(lib.pdlp_set_exchange_chunks(h, ch)); info = eng.split_info(0); N_.check(lib.pdlp_set_exchange_chunks(h, 1))
+        print(f"   exchange in {ch} pieces (slots {info['local_groups']} + {info['other_groups']}): min {c[0]:.3f} med {c[1]:.3f} ms", flush=True)

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PDLP_LIB", os.path.join(_HERE, "libpdlp_hip.so"))   # PDLP_LIB: profiling/ablation builds
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 PDLP_F32, PDLP_F64, PDLP_MIXED = 0, 1, 2
 CUR, AVG, PREV = 0, 1, 2
 (BUF_X_CUR, BUF_X_PREV, BUF_XBAR, BUF_X_AVG, BUF_Y_CUR, BUF_Y_PREV, BUF_Y_AVG, BUF_RED, BUF_X_SUM, BUF_Y_SUM,
@@ -67,6 +67,9 @@ SIGNATURES = {
     "pdlp_adaptive_reduce": (_I, [_H]),
     "pdlp_adaptive_update": (_I, [_H]),
     "pdlp_iterate": (_I, [_H, _I, _I]),
+    "pdlp_set_exchange_chunks": (_I, [_H, _I]),
+    "pdlp_exchange_plan": (_I, [_H, _I, C.POINTER(C.c_int32), C.POINTER(_I64)]),
+    "pdlp_half_chunk": (_I, [_H, _I, _I]),
     "pdlp_comm_load": (_I, [C.c_char_p]),
     "pdlp_comm_unique_id": (_I, [C.c_char_p, _P]),
     "pdlp_comm_init": (_I, [_H, C.c_char_p, _P, _I, _I]),

@@ -35,6 +35,8 @@ constexpr int NNZ_CAP = 2048;    // non-zeros staged in LDS per row block
 constexpr int ROWS_CAP = 256;    // rows per row block (one epilogue lane each at most)
 constexpr int MAX_GRID = 2048;   // 256 CUs x 8 workgroups
 constexpr int NACC = 4;          // partial sums a kernel may produce
+constexpr int MAX_CHUNKS = 4;    // chunks of the exchange of a gathered vector (sharded problems)
+constexpr int MAX_PHASE = MAX_CHUNKS + 2;
 
 // indices into the device scalar block (double[PDLP_NSCAL])
 enum { S_ETA = 0, S_OMEGA, S_THETA, S_TAU, S_SIGMA, S_WPEND, S_ETASUM, S_K, S_INV1PT, S_ACCEPT, S_ETABAR, S_DEN };
@@ -110,6 +112,9 @@ struct Rccl {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;            // optional (chunked exchange): grouped in-place broadcasts
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     int last_error = 0;
 };
@@ -134,6 +139,9 @@ int rccl_load(const char* path)
     r.AllGather = (decltype(r.AllGather))dlsym(lib, "ncclAllGather");
     r.AllReduce = (decltype(r.AllReduce))dlsym(lib, "ncclAllReduce");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    r.Broadcast = (decltype(r.Broadcast))dlsym(lib, "ncclBroadcast");
+    r.GroupStart = (decltype(r.GroupStart))dlsym(lib, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))dlsym(lib, "ncclGroupEnd");
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.AllReduce) return PDLP_ERR_COMM;
     g_rccl = r;
     return PDLP_OK;
@@ -168,8 +176,17 @@ struct Schedule {
     // sharded problems: the panels lying wholly inside the locally owned block of the gathered vector, [loc_pa, loc_pb),
     // can be multiplied before the all-gather of that vector has finished (pdlp_*_half_begin)
     int loc_pa = 0, loc_pb = 0;
-    int slotsA = 0, slotsB = 0;   // panel groups (= partial row sum slots) of the local and of the other panels
+    int slotsA = 0, slotsB = 0;   // panel groups (= partial row sum slots) of the local and of all the other panels
     bool pending = false;         // the local panels of the next product are already in rowsum[0 .. slotsA)
+    // the exchange of the gathered vector in `nphase - 1` chunks (pdlp_set_exchange_chunks): chunk c moves elements
+    // [sb[c], sb[c+1]) of EVERY rank's block; a panel belongs to the phase with which its last foreign entry arrives
+    // (phase 0: the panels of the own block, phase 1 + c: chunk c).  ptab holds the panels phase by phase.
+    int32_t* ptab = nullptr;      // device, room for every panel of the matrix
+    int64_t ptab_cap = 0;
+    int nphase = 0;               // 0: product not split
+    int ph_off[MAX_PHASE] = {0}, ph_cnt[MAX_PHASE] = {0}, ph_slots[MAX_PHASE] = {0}, ph_slot0[MAX_PHASE] = {0};
+    int64_t sb[MAX_PHASE] = {0};
+    int chunks_done = 0;          // chunk phases of the pending product already launched (pdlp_half_chunk)
 };
 
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
@@ -236,6 +253,9 @@ struct pdlp_solver {
     bool delta, anchors_valid, dy_folded;
     ncclComm_t comm;              // RCCL communicator of a sharded problem (pdlp_comm_init), or null: the caller does the exchange
     int comm_rank, comm_size;
+    int xchunks;                  // chunks of the exchange of a gathered vector (pdlp_set_exchange_chunks); 1: one all-gather
+    hipStream_t cstream;          // the chunks travel on this stream while the handle's stream multiplies what has arrived
+    hipEvent_t ev_vec, ev_chunk[MAX_CHUNKS];
     char* ktyr;                   // [nl] float64 running K'y
     float *gdx, *gdy;             // full-length float32 difference vectors the float32 kernels gather from
     int64_t nl, ml;               // local variable / constraint counts
@@ -294,6 +314,9 @@ void free_handle(pdlp_handle h)
     drop_graphs(h);
     if (h->comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
     if (h->gstream) { (void)hipStreamSynchronize(h->gstream); (void)hipStreamDestroy(h->gstream); }
+    if (h->cstream) { (void)hipStreamSynchronize(h->cstream); (void)hipStreamDestroy(h->cstream); }
+    if (h->ev_vec) (void)hipEventDestroy(h->ev_vec);
+    for (auto& e : h->ev_chunk) if (e) (void)hipEventDestroy(e);
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->ev_out) (void)hipEventDestroy(h->ev_out);
     delete h;
@@ -303,14 +326,22 @@ void free_handle(pdlp_handle h)
 // rowsum[slot0 .. slot0 + vgroups); the epilogue functor is not used by these launches
 template <typename T, typename TV>
 void launch_tiled_groups(pdlp_handle h, const Schedule& s, int rows, const void* vin, hipStream_t stream, int vgroups, int vtotal,
-                         int skip_lo, int skip_len, int slot0)
+                         const int32_t* ptab, int slot0)
 {
+    if (vtotal <= 0 || vgroups <= 0) return;
     const int ppg = (vtotal + vgroups - 1) / vgroups;
     const int groups = (vtotal + ppg - 1) / ppg;          // no group without panels
     StoreEpi<T> none{nullptr};
     hipLaunchKernelGGL((k_tiled_fused<T, TV, StoreEpi<T>, false>), dim3(s.t.nblk * groups), dim3(TNT), 0, stream, s.t.idx,
-                       (const TV*)s.t.val, s.t.tile_ptr, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, ppg, vtotal, skip_lo,
-                       skip_len, slot0, (const T*)vin, (T*)h->rowsum, h->rs_stride, (const T*)nullptr, none, (double*)nullptr);
+                       (const TV*)s.t.val, s.t.tile_ptr, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, ppg, vtotal, ptab,
+                       slot0, (const T*)vin, (T*)h->rowsum, h->rs_stride, (const T*)nullptr, none, (double*)nullptr);
+}
+
+// one phase of a split product (0: the own block's panels, 1 + c: the panels completed by chunk c of the exchange)
+template <typename T, typename TV>
+void launch_phase(pdlp_handle h, const Schedule& s, int rows, const void* vin, hipStream_t stream, int phase)
+{
+    launch_tiled_groups<T, TV>(h, s, rows, vin, stream, s.ph_slots[phase], s.ph_cnt[phase], s.ptab + s.ph_off[phase], s.ph_slot0[phase]);
 }
 
 // one product with K (or K') over the vector vin with the epilogue fused: T = type of vin, of the row sums and of what the
@@ -323,6 +354,7 @@ int launch_mat(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* 
         // before the row-sum scratch is reused
         HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_out, 0));
         h->sK.pending = h->sKT.pending = false;
+        h->sK.chunks_done = h->sKT.chunks_done = 0;
     }
     const Schedule& s = transpose ? h->sKT : h->sK;
     if (s.nblk == 0) return PDLP_OK;
@@ -341,16 +373,18 @@ int launch_mat(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* 
         if (s.t.groups == 1 && !(s.pending && h->use_split)) {
             hipLaunchKernelGGL((k_tiled_fused<T, TV, Epi, true>), dim3(s.t.nblk), dim3(TNT), 0, h->stream, s.t.idx, (const TV*)s.t.val,
                                s.t.tile_ptr, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, s.t.npanel, s.t.npanel,
-                               s.t.npanel, 0, 0, (const T*)vin, (T*)h->rowsum, h->rs_stride, extra, epi, partials);
+                               (const int32_t*)nullptr, 0, (const T*)vin, (T*)h->rowsum, h->rs_stride, extra, epi, partials);
         } else if (s.pending && h->use_split) {
-            // the local panels were multiplied by pdlp_*_half_begin on the side stream; now the others, then the sum
-            launch_tiled_groups<T, TV>(h, s, rows, vin, h->stream, s.slotsB, s.t.npanel - (s.loc_pb - s.loc_pa), s.loc_pa,
-                                   s.loc_pb - s.loc_pa, s.slotsA);
+            // the local panels were multiplied by pdlp_*_half_begin on the side stream (and the first chunks' panels by
+            // pdlp_half_chunk as they arrived); now the remaining chunks' panels, then the sum over all slots in fixed order
+            Schedule& sm = transpose ? h->sKT : h->sK;
+            for (int ph = 1 + sm.chunks_done; ph < s.nphase; ++ph) launch_phase<T, TV>(h, s, rows, vin, h->stream, ph);
+            sm.chunks_done = 0;
             HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_out, 0));
             hipLaunchKernelGGL((k_rowsum_epilogue<T, Epi>), dim3(grid_for(rows)), dim3(BLOCK), 0, h->stream, (const T*)h->rowsum,
                                s.slotsA + s.slotsB, h->rs_stride, rows, extra, epi, partials);
         } else {
-            launch_tiled_groups<T, TV>(h, s, rows, vin, h->stream, s.t.groups, s.t.npanel, s.t.npanel, 0, 0);
+            launch_tiled_groups<T, TV>(h, s, rows, vin, h->stream, s.t.groups, s.t.npanel, (const int32_t*)nullptr, 0);
             hipLaunchKernelGGL((k_rowsum_epilogue<T, Epi>), dim3(grid_for(rows)), dim3(BLOCK), 0, h->stream, (const T*)h->rowsum,
                                s.t.groups, h->rs_stride, rows, extra, epi, partials);
         }
@@ -541,21 +575,47 @@ template <typename T> void kkt_finish_t(const double* r, double omega_d, double*
     out[0] = pr; out[1] = dr; out[2] = gap; out[3] = p; out[4] = adj; out[5] = kkt;
 }
 
-// panel groups of the split product of one matrix (see Schedule): the local panels get their share of the slots
-void configure_split(pdlp_handle h, bool transpose)
+// panel groups of the split product of one matrix (see Schedule): which panels belong to which phase of the exchange, and how
+// many workgroup groups (= partial row sum slots) every phase gets
+int configure_split(pdlp_handle h, bool transpose)
 {
     Schedule& s = transpose ? h->sKT : h->sK;
     s.loc_pa = s.loc_pb = s.slotsA = s.slotsB = 0;
     s.pending = false;
-    if (!s.tiled) return;
+    s.nphase = 0; s.chunks_done = 0;
+    if (!s.tiled) return PDLP_OK;
     const int64_t lo = transpose ? h->p.row0 : h->p.col0, hi = transpose ? h->p.row1 : h->p.col1;
     const int64_t total = transpose ? h->p.m : h->p.n;
-    if (lo == 0 && hi == total) return;                               // not sharded: nothing to wait for
-    const int64_t W = (int64_t)1 << s.t.lw;
-    const int pa = (int)((lo + W - 1) / W), pb = hi == total ? s.t.npanel : (int)(hi / W);
-    const int nloc = pb - pa, nrem = s.t.npanel - nloc;
-    if (nloc <= 0 || nrem <= 0 || h->rs_groups < 2) return;
-    // Measured on shard-shaped matrices with a spin kernel standing in for the gather (tools/split_timing.py):
+    if (lo == 0 && hi == total) return PDLP_OK;                       // not sharded: nothing to wait for
+    const int64_t W = (int64_t)1 << s.t.lw, B = hi - lo;
+    const int npanel = s.t.npanel;
+    const int pa = (int)((lo + W - 1) / W), pb = hi == total ? npanel : (int)(hi / W);
+    const int nloc = pb - pa, nrem = npanel - nloc;
+    if (nloc <= 0 || nrem <= 0 || h->rs_groups < 2 || !s.ptab || npanel > s.ptab_cap || B <= 0 || lo % B != 0) return PDLP_OK;
+    // chunk c of the exchange moves elements [sb[c], sb[c+1]) of every rank's block (multiples of 64 elements: 256-byte pieces)
+    int C = h->xchunks < 1 ? 1 : (h->xchunks > MAX_CHUNKS ? MAX_CHUNKS : h->xchunks);
+    if (B < (int64_t)64 * C) C = 1;
+    for (int c = 0; c <= C; ++c) s.sb[c] = c == C ? B : (c * B / C) / 64 * 64;
+    // a panel is complete once the last of its foreign entries has arrived
+    std::vector<int> phase((size_t)npanel);
+    int cnt[MAX_PHASE] = {0};
+    for (int p = 0; p < npanel; ++p) {
+        int ph = 0;
+        if (p < pa || p >= pb) {
+            const int64_t c0 = (int64_t)p * W, c1 = (c0 + W < total) ? c0 + W : total;
+            ph = 1;
+            for (int64_t q = c0 / B; q <= (c1 - 1) / B; ++q) {
+                if (q * B == lo) continue;                               // the own block is there already
+                const int64_t off_hi = ((c1 < (q + 1) * B) ? c1 : (q + 1) * B) - 1 - q * B;
+                int c = 0;
+                while (c + 1 < C && s.sb[c + 1] <= off_hi) ++c;
+                if (1 + c > ph) ph = 1 + c;
+            }
+        }
+        phase[(size_t)p] = ph;
+        ++cnt[ph];
+    }
+    // Slots.  Measured on shard-shaped matrices with a spin kernel standing in for the gather (tools/split_timing.py):
     // each launch must fit ONE round of workgroups (2 per CU) or its tail costs more than the overlap gains; the
     // other panels take as many groups as fit; the local panels enough groups that a workgroup walks <= ~13 panels
     // and is done by the time the gather is.  10M x 10M: 8 ranks (2 + 8 groups) 0.402 -> 0.380 ms per half-step,
@@ -563,21 +623,52 @@ void configure_split(pdlp_handle h, bool transpose)
     const int round_slots = 2 * 256;
     int fit = round_slots / (s.t.nblk > 0 ? s.t.nblk : 1);
     fit = fit < 1 ? 1 : fit;
-    int b = fit < nrem ? fit : nrem;
+    auto norm = [](int g, int n) { if (n <= 0) return 0; g = g < 1 ? 1 : (g > n ? n : g); const int ppg = (n + g - 1) / g; return (n + ppg - 1) / ppg; };
     int a = (nloc + 12) / 13;
     a = a > fit ? fit : a;
     a = a > nloc ? nloc : a;
-    if (a + b > h->rs_groups) b = h->rs_groups - a;
-    if (a < 1 || b < 1) return;
-    int S = a + b;
-    if (const char* ov = std::getenv("PDLP_SPLIT_SLOTS")) {           // experiments: "local,other"
-        int oa = 0, ob = 0;
-        if (std::sscanf(ov, "%d,%d", &oa, &ob) == 2 && oa >= 1 && ob >= 1 && oa + ob <= h->rs_groups) { a = oa; S = oa + ob; }
+    int g[MAX_PHASE] = {0};
+    if (C == 1) {
+        int b = fit < nrem ? fit : nrem;
+        if (a + b > h->rs_groups) b = h->rs_groups - a;
+        if (a < 1 || b < 1) return PDLP_OK;
+        int S = a + b;
+        if (const char* ov = std::getenv("PDLP_SPLIT_SLOTS")) {           // experiments: "local,other"
+            int oa = 0, ob = 0;
+            if (std::sscanf(ov, "%d,%d", &oa, &ob) == 2 && oa >= 1 && ob >= 1 && oa + ob <= h->rs_groups) { a = oa; S = oa + ob; }
+        }
+        g[0] = norm(a, nloc);
+        g[1] = norm(S - a, nrem);
+    } else {
+        // every chunk's launch fills the chip by itself where it can; fewer groups per chunk when the scratch runs out
+        int left = h->rs_groups - a;
+        if (a < 1 || left < C) return PDLP_OK;
+        g[0] = norm(a, nloc);
+        int want[MAX_PHASE] = {0}, sum = 0;
+        for (int c = 0; c < C; ++c) { want[1 + c] = cnt[1 + c] > 0 ? (fit < cnt[1 + c] ? fit : cnt[1 + c]) : 0; sum += want[1 + c]; }
+        for (int c = 0; c < C; ++c) {
+            int w = want[1 + c];
+            if (sum > left && w > 0) { w = (int)((int64_t)w * left / sum); w = w < 1 ? 1 : w; }
+            g[1 + c] = norm(w, cnt[1 + c]);
+        }
     }
-    auto norm = [](int g, int n) { g = g > n ? n : g; const int ppg = (n + g - 1) / g; return (n + ppg - 1) / ppg; };
+    // the table: panels phase by phase, ascending inside a phase
+    std::vector<int32_t> tab((size_t)npanel);
+    int off = 0, slot = 0;
+    s.nphase = 1 + C;
+    for (int ph = 0; ph < s.nphase; ++ph) {
+        s.ph_off[ph] = off; s.ph_cnt[ph] = cnt[ph]; s.ph_slots[ph] = g[ph]; s.ph_slot0[ph] = slot;
+        for (int p = 0; p < npanel; ++p)
+            if (phase[(size_t)p] == ph) tab[(size_t)off++] = p;
+        slot += g[ph];
+    }
+    if (slot > h->rs_groups) { s.nphase = 0; return PDLP_OK; }
+    HIP_TRY(hipMemcpyAsync(s.ptab, tab.data(), (size_t)npanel * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));                          // (the host vector goes away)
     s.loc_pa = pa; s.loc_pb = pb;
-    s.slotsA = norm(a, nloc);
-    s.slotsB = norm(S - a, nrem);
+    s.slotsA = g[0];
+    s.slotsB = slot - g[0];
+    return PDLP_OK;
 }
 
 template <typename T> int half_begin_t(pdlp_handle h, bool transpose, const void* vin)
@@ -587,14 +678,29 @@ template <typename T> int half_begin_t(pdlp_handle h, bool transpose, const void
     const int rows = (int)(transpose ? h->nl : h->ml);
     HIP_TRY(hipEventRecord(h->ev_in, h->stream));
     HIP_TRY(hipStreamWaitEvent(h->gstream, h->ev_in, 0));
-    if (h->delta) launch_tiled_groups<float, float>(h, s, rows, transpose ? (const void*)h->gdy : (const void*)h->gdx, h->gstream, s.slotsA,
-                                                    s.loc_pb - s.loc_pa, 0, s.loc_pa, 0);
-    else if (std::is_same<T, double>::value && h->mixed)
-        launch_tiled_groups<double, float>(h, s, rows, vin, h->gstream, s.slotsA, s.loc_pb - s.loc_pa, 0, s.loc_pa, 0);
-    else launch_tiled_groups<T, T>(h, s, rows, vin, h->gstream, s.slotsA, s.loc_pb - s.loc_pa, 0, s.loc_pa, 0);
+    if (h->delta) launch_phase<float, float>(h, s, rows, transpose ? (const void*)h->gdy : (const void*)h->gdx, h->gstream, 0);
+    else if (std::is_same<T, double>::value && h->mixed) launch_phase<double, float>(h, s, rows, vin, h->gstream, 0);
+    else launch_phase<T, T>(h, s, rows, vin, h->gstream, 0);
     HIP_TRY(hipEventRecord(h->ev_out, h->gstream));
     HIP_TRY(hipGetLastError());
     s.pending = true;
+    s.chunks_done = 0;
+    return PDLP_OK;
+}
+
+// the panels that chunk `chunk` of the exchange completes, on the handle's stream (the caller has made that stream wait for the
+// chunk); the last chunk's panels are launched by the half-step itself, together with the sum and the epilogue
+template <typename T> int half_chunk_t(pdlp_handle h, bool transpose, const void* vin, int chunk)
+{
+    Schedule& s = transpose ? h->sKT : h->sK;
+    if (!s.pending || s.nphase == 0) return PDLP_OK;           // the product is not split this time: the half-step does it all
+    if (chunk != s.chunks_done || chunk + 2 >= s.nphase + 0) return chunk + 2 == s.nphase ? PDLP_OK : PDLP_ERR_STATE;
+    const int rows = (int)(transpose ? h->nl : h->ml);
+    if (h->delta) launch_phase<float, float>(h, s, rows, transpose ? (const void*)h->gdy : (const void*)h->gdx, h->stream, 1 + chunk);
+    else if (std::is_same<T, double>::value && h->mixed) launch_phase<double, float>(h, s, rows, vin, h->stream, 1 + chunk);
+    else launch_phase<T, T>(h, s, rows, vin, h->stream, 1 + chunk);
+    HIP_TRY(hipGetLastError());
+    ++s.chunks_done;
     return PDLP_OK;
 }
 
@@ -948,8 +1054,8 @@ int check_problem(const pdlp_problem* p)
 // cannot fill 2 x 256 CUs, i.e. below about 10.5M rows
 inline int64_t rowsum_groups(int64_t rows)
 {
-    if (rows <= (int64_t)TNT * TRPT_MAX_ANY * 128) return 16;     // (small shards: room to split local / other panels finely)
-    return rows <= (int64_t)TNT * TRPT_MAX_ANY * 512 ? 8 : 1;
+    if (rows <= (int64_t)TNT * 40 * 128) return 24;               // (small shards: room for the local panels and several chunks' groups)
+    return rows <= (int64_t)TNT * 40 * 512 ? 8 : 1;
 }
 
 struct Carve {
@@ -999,6 +1105,9 @@ int64_t layout(const pdlp_problem* p, int64_t nnzK, int64_t nnzKT, int64_t* offs
     offs[k++] = c.take(mixed ? p->m * 4 : 0);                     // 37    gdy
     offs[k++] = c.take(ml * es);                                  // 38    kx_sum  (running sum of w_k K x_k)
     offs[k++] = c.take(nl * es);                                  // 39    kty_sum (running sum of w_k K'y_k)
+    const bool sharded = nl != p->n || ml != p->m;                // panel tables of the split products (sharded problems only)
+    offs[k++] = c.take(sharded ? ((p->n >> 4) + 8) * 4 : 0);      // 40    panels of K by phase  (panel width >= 16 columns)
+    offs[k++] = c.take(sharded ? ((p->m >> 4) + 8) * 4 : 0);      // 41    panels of K'
     return c.off;
 }
 
@@ -1022,7 +1131,7 @@ int read_last_rowptr(const int32_t* rp, int64_t rows, int64_t* nnz, hipStream_t 
 // ================================================================================================
 extern "C" {
 
-int pdlp_abi_version(void) { return 12; }  // 12: count words of a tile laid out for coalesced loads; 11: pdlp_comm_load; 10: pdlp_set_anchors; 9: pdlp_attach_sorted; 8: running products, pdlp_flush_average(h, adaptive); 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
+int pdlp_abi_version(void) { return 13; }  // 13: chunked exchange (pdlp_set_exchange_chunks, pdlp_exchange_plan, pdlp_half_chunk); 12: count words of a tile laid out for coalesced loads; 11: pdlp_comm_load; 10: pdlp_set_anchors; 9: pdlp_attach_sorted; 8: running products, pdlp_flush_average(h, adaptive); 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
 
 const char* pdlp_strerror(int code)
 {
@@ -1075,6 +1184,8 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     h->es = p->dtype == PDLP_F32 ? 4 : 8;
     h->mixed = p->dtype == PDLP_MIXED;
     h->comm = nullptr; h->comm_rank = 0; h->comm_size = 1;
+    h->xchunks = 1; h->cstream = nullptr; h->ev_vec = nullptr;
+    for (auto& e : h->ev_chunk) e = nullptr;
     h->delta = false; h->anchors_valid = false; h->dy_folded = false;
     h->nl = nl;
     h->ml = ml;
@@ -1095,6 +1206,10 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     h->ktyb[0] = w + offs[33]; h->ktyb[1] = w + offs[34];
     h->ktyr = w + offs[35]; h->gdx = (float*)(w + offs[36]); h->gdy = (float*)(w + offs[37]);
     h->kx_sum = w + offs[38]; h->kty_sum = w + offs[39];
+    if (nl != p->n || ml != p->m) {
+        h->sK.ptab = (int32_t*)(w + offs[40]); h->sK.ptab_cap = (p->n >> 4) + 8;
+        h->sKT.ptab = (int32_t*)(w + offs[41]); h->sKT.ptab_cap = (p->m >> 4) + 8;
+    }
     h->since_reset = 0; h->kty_tail_done = false; h->avg_products = false; h->sums_broken = false; h->cur_kx_cached = false;
     h->no_running = std::getenv("PDLP_RUNNING_KKT") != nullptr && std::getenv("PDLP_RUNNING_KKT")[0] == '0';
     h->kty_cur = -1;
@@ -1196,7 +1311,7 @@ int pdlp_attach_tiles(pdlp_handle h, int transpose, const pdlp_tiles* t)
     if (!h) return PDLP_ERR_INVALID;
     Schedule& s = transpose ? h->sKT : h->sK;
     drop_graphs(h);               // captured launches name the old kernel and arrays
-    if (!t) { s.tiled = false; configure_split(h, transpose != 0); return PDLP_OK; }
+    if (!t) { s.tiled = false; return configure_split(h, transpose != 0); }
     const int64_t rows = transpose ? h->nl : h->ml;
     const int rpt_max = h->p.dtype == PDLP_F64 ? TileCfg<double, double>::RPT_MAX : TileCfg<float, float>::RPT_MAX;   // (mixed: float32 tiles)
     const int cap_max = h->p.dtype == PDLP_F64 ? TileCfg<double, double>::CAP : TileCfg<float, float>::CAP;
@@ -1215,8 +1330,7 @@ int pdlp_attach_tiles(pdlp_handle h, int transpose, const pdlp_tiles* t)
         return PDLP_ERR_INVALID;
     s.t = *t;
     s.tiled = true;
-    configure_split(h, transpose != 0);
-    return PDLP_OK;
+    return configure_split(h, transpose != 0);
 }
 
 int pdlp_schedule_info(pdlp_handle h, int transpose, int32_t* nblk, const int32_t** blocks)
@@ -1334,6 +1448,40 @@ int pdlp_split_info(pdlp_handle h, int transpose, int32_t out[4])
     return PDLP_OK;
 }
 
+int pdlp_set_exchange_chunks(pdlp_handle h, int chunks)
+{
+    if (!h || chunks < 1 || chunks > MAX_CHUNKS) return PDLP_ERR_INVALID;
+    if (h->sK.pending || h->sKT.pending) return PDLP_ERR_STATE;       // not in the middle of a split product
+    h->xchunks = chunks;
+    drop_graphs(h);
+    int rc = configure_split(h, false);
+    if (rc == PDLP_OK) rc = configure_split(h, true);
+    return rc;
+}
+
+int pdlp_exchange_plan(pdlp_handle h, int transpose, int32_t* nchunks, int64_t bounds[5])
+{
+    if (!h || !nchunks || !bounds) return PDLP_ERR_INVALID;
+    const Schedule& s = transpose ? h->sKT : h->sK;
+    const int64_t B = transpose ? h->ml : h->nl;
+    if (s.nphase == 0) {                          // the product is not split: one exchange of the whole block
+        *nchunks = 1;
+        bounds[0] = 0; bounds[1] = B;
+        for (int c = 2; c < 5; ++c) bounds[c] = B;
+        return PDLP_OK;
+    }
+    *nchunks = s.nphase - 1;
+    for (int c = 0; c < 5; ++c) bounds[c] = c < s.nphase ? s.sb[c] : B;
+    return PDLP_OK;
+}
+
+int pdlp_half_chunk(pdlp_handle h, int transpose, int chunk)
+{
+    if (!h || chunk < 0 || chunk >= MAX_CHUNKS) return PDLP_ERR_INVALID;
+    if (transpose) return DISPATCH(h, half_chunk_t, h, true, h->yb[h->ix_cur], chunk);
+    return DISPATCH(h, half_chunk_t, h, false, h->xbar, chunk);
+}
+
 int pdlp_tile_limits(pdlp_handle h, int32_t out[4])
 {
     if (!h || !out) return PDLP_ERR_INVALID;
@@ -1443,8 +1591,57 @@ int comm_all_gather(pdlp_handle h, void* full, int64_t count, bool f32)
     return PDLP_OK;
 }
 
+// the exchange of one gathered vector in the chunks of its product's plan: chunk c = elements [sb[c], sb[c+1]) of every rank's
+// block, as one group of in-place broadcasts (one root per rank) on the communication stream; ev_chunk[c] marks its arrival
+int comm_exchange_chunked(pdlp_handle h, const Schedule& s, void* full, int64_t block, bool f32)
+{
+    const size_t esz = f32 ? 4 : 8;
+    const int C = s.nphase - 1;
+    HIP_TRY(hipEventRecord(h->ev_vec, h->stream));               // this rank's block is final
+    HIP_TRY(hipStreamWaitEvent(h->cstream, h->ev_vec, 0));
+    for (int c = 0; c < C; ++c) {
+        const int64_t lo = s.sb[c], cnt = s.sb[c + 1] - s.sb[c];
+        if (cnt > 0) {
+            RCCL_TRY(g_rccl.GroupStart());
+            for (int q = 0; q < h->comm_size; ++q) {
+                char* ptr = (char*)full + ((size_t)q * block + lo) * esz;
+                const ncclResult_t r = g_rccl.Broadcast(ptr, ptr, (size_t)cnt, f32 ? ncclFloat32 : ncclFloat64, q, h->comm, h->cstream);
+                if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); g_rccl.last_error = (int)r; return PDLP_ERR_COMM; }
+            }
+            RCCL_TRY(g_rccl.GroupEnd());
+        }
+        HIP_TRY(hipEventRecord(h->ev_chunk[c], h->cstream));
+    }
+    return PDLP_OK;
+}
+
+// one half-step of a sharded iteration with the exchange of its input in front: K xbar (transpose 0) or K'y (1, not after the
+// last iteration of the call).  Chunked plans: the chunks travel on the communication stream, and the handle's stream multiplies
+// the panels a chunk completes as soon as it has arrived; the last chunk's panels, the sum and the epilogue are the half-step.
+int sharded_exchange_and_begin(pdlp_handle h, bool transpose, int adaptive, bool begin)
+{
+    int rc;
+    const bool vec32 = h->p.dtype == PDLP_F32;
+    const Schedule& s = transpose ? h->sKT : h->sK;
+    void* full = transpose ? (h->delta ? (void*)h->gdy : (void*)h->yb[h->ix_cur]) : (h->delta ? (void*)h->gdx : (void*)h->xbar);
+    const int64_t block = transpose ? h->ml : h->nl;
+    const bool f32 = h->delta || vec32;
+    // the panels that meet this rank's own block are multiplied (side stream) while the other blocks are on the wire
+    if (begin && (rc = (transpose ? pdlp_primal_half_begin(h) : pdlp_dual_half_begin(h, adaptive))) != PDLP_OK) return rc;
+    const bool chunked = s.pending && s.nphase > 2 && h->cstream && g_rccl.Broadcast && g_rccl.GroupStart && g_rccl.GroupEnd;
+    if (!chunked) return comm_all_gather(h, full, block, f32);
+    if ((rc = comm_exchange_chunked(h, s, full, block, f32)) != PDLP_OK) return rc;
+    const int C = s.nphase - 1;
+    for (int c = 0; c + 1 < C; ++c) {
+        HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_chunk[c], 0));
+        if ((rc = pdlp_half_chunk(h, transpose ? 1 : 0, c)) != PDLP_OK) return rc;
+    }
+    HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_chunk[C - 1], 0));
+    return PDLP_OK;
+}
+
 // the iterations of a sharded problem with the exchange inside the library: the same sequence as PdlpEngine.iterate drives
-// through torch.distributed (engine.py), all of it enqueued on the handle's stream -- one call per restart period, no host
+// through torch.distributed (engine.py), all of it enqueued on the handle's streams -- one call per restart period, no host
 // work between the kernels and the collectives
 int iterate_sharded(pdlp_handle h, int iters, int adaptive)
 {
@@ -1457,16 +1654,11 @@ int iterate_sharded(pdlp_handle h, int iters, int adaptive)
     }
     for (int it = 0; it < iters; ++it) {
         if ((rc = pdlp_primal_half(h, adaptive)) != PDLP_OK) return rc;
-        // the panels of K that meet this rank's own block of xbar are multiplied (side stream) while the other blocks are on the wire
-        if ((rc = pdlp_dual_half_begin(h, adaptive)) != PDLP_OK) return rc;
-        if (h->delta) rc = comm_all_gather(h, h->gdx, h->nl, true);
-        else rc = comm_all_gather(h, h->xbar, h->nl, vec32);
-        if (rc != PDLP_OK) return rc;
+        if ((rc = sharded_exchange_and_begin(h, false, adaptive, true)) != PDLP_OK) return rc;      // xbar (delta mode: x+ - x)
         if ((rc = pdlp_dual_half(h, adaptive)) != PDLP_OK) return rc;
-        if (it + 1 < iters && (rc = pdlp_primal_half_begin(h)) != PDLP_OK) return rc;
-        if (h->delta) rc = comm_all_gather(h, h->gdy, h->ml, true);
-        else rc = comm_all_gather(h, h->yb[h->ix_cur], h->ml, vec32);
-        if (rc != PDLP_OK) return rc;
+        // the new y (delta mode: y+ - y) -- final: a rejected adaptive step is kept, quirk Q1; its product starts only if
+        // another iteration follows in this call
+        if ((rc = sharded_exchange_and_begin(h, true, adaptive, it + 1 < iters)) != PDLP_OK) return rc;
         if (adaptive) {
             if ((rc = pdlp_adaptive_reduce(h)) != PDLP_OK) return rc;
             RCCL_TRY(g_rccl.AllReduce(h->red, h->red, 3, ncclFloat64, ncclSum, h->comm, h->stream));
@@ -1506,6 +1698,12 @@ int pdlp_comm_init(pdlp_handle h, const char* rccl_path, const void* id128, int 
     std::memcpy(&id, id128, sizeof(id));
     RCCL_TRY(g_rccl.CommInitRank(&h->comm, nranks, id, rank));
     h->comm_rank = rank; h->comm_size = nranks;
+    if (!h->cstream) {           // (chunked exchange: without these it stays one all-gather on the handle's stream)
+        bool ok = hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&h->ev_vec, hipEventDisableTiming) == hipSuccess;
+        for (auto& e : h->ev_chunk) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        if (!ok) { if (h->cstream) (void)hipStreamDestroy(h->cstream); h->cstream = nullptr; (void)hipGetLastError(); }
+    }
     return PDLP_OK;
 }
 

@@ -46,6 +46,23 @@ class Comm:
         else:
             self.dist.all_gather_into_tensor(full, mine, group=self.group)
 
+    def all_gather_piece(self, full: torch.Tensor, lo: int, hi: int):
+        """elements [lo, hi) of EVERY rank's block of ``full`` (this rank's are in place); returns a handle whose ``wait()`` makes the
+        current stream wait for the piece (None: already there) -- the pieces of a chunked exchange queue up behind each other while
+        the products of the earlier ones run"""
+        B = full.numel() // self.world
+        views = [full[q * B + lo:q * B + hi] for q in range(self.world)]
+        if hi <= lo:
+            return None
+        if self.backend == "gloo" and full.is_cuda:     # test path: through the host, synchronous
+            parts = [torch.empty(hi - lo, dtype=full.dtype) for _ in range(self.world)]
+            self.dist.all_gather(parts, views[self.rank].cpu(), group=self.group)
+            for q, part in enumerate(parts):
+                if q != self.rank:
+                    views[q].copy_(part)
+            return None
+        return self.dist.all_gather(views, views[self.rank], group=self.group, async_op=True)
+
     def all_reduce_sum(self, t: torch.Tensor, op=None):
         op = self.dist.ReduceOp.SUM if op is None else op
         if self.backend == "gloo" and t.is_cuda:
@@ -130,9 +147,12 @@ class PdlpEngine:
             self.exact = PdlpEngine(m, n, m_ineq, exact[0], exact[1], c, q, l, u, rows=rows, cols=cols, comm=comm, tiles=False)
         self._sorted = [None, None]
         self._mv_work = {}
+        self.xchunks, self._plans = 1, {}
         self.tiles = [None, None]
         self.kernels = ["csr", "csr"]
         self._maybe_attach_tiles()
+        if self.comm is not None and tiles and int(os.environ.get("PDLP_EXCHANGE_CHUNKS", "1")) > 1:
+            self.set_exchange_chunks(int(os.environ["PDLP_EXCHANGE_CHUNKS"]))
         self.delta = False
         if self.mixed and (delta if delta is not None else os.environ.get("PDLP_DELTA", "1") != "0"):
             self.set_delta(True)
@@ -241,6 +261,7 @@ class PdlpEngine:
     def attach_tiles(self, transpose: int, t: Optional["_tiled.Tiles"]):
         if t is None:
             N.check(self.lib.pdlp_attach_tiles(self.h, int(transpose), None), "pdlp_attach_tiles")
+            self._plans = {}
             self.tiles[int(transpose)] = None
             self.kernels[int(transpose)] = "csr"
             return
@@ -256,6 +277,7 @@ class PdlpEngine:
         desc = N.PdlpTiles(t.lw, t.rpt, t.cap, t.nblk, t.npanel, t.groups, t.idx.data_ptr(), t.val.data_ptr(), t.tile_ptr.data_ptr(),
                            t.cnt.data_ptr(), *rem)
         N.check(self.lib.pdlp_attach_tiles(self.h, int(transpose), C.byref(desc)), "pdlp_attach_tiles")
+        self._plans = {}
         self.tiles[int(transpose)] = t       # keep the arrays alive
         self.kernels[int(transpose)] = ("tiled" if t.groups == 1 else f"tiled/{t.groups} groups") + (f" + remainder {t.nrem}" if t.nrem else "")
 
@@ -401,6 +423,37 @@ class PdlpEngine:
             self._gather(N.BUF_Y_CUR)
         N.check(self.lib.pdlp_refresh_products(self.h), "pdlp_refresh_products")
 
+    def set_exchange_chunks(self, chunks: int):
+        """Sharded, tiled products: move the gathered vector in ``chunks`` pieces (piece c = a slice of EVERY rank's block) and
+        multiply the panels a piece completes while the next piece is on the wire (include/pdlp_hip.h, pdlp_set_exchange_chunks).
+        1 = one all-gather per product.  Every rank must choose the same number."""
+        N.check(self.lib.pdlp_set_exchange_chunks(self.h, int(chunks)), "pdlp_set_exchange_chunks")
+        self.xchunks = int(chunks)
+        self._plans = {}
+
+    def exchange_plan(self, transpose: int) -> list:
+        """[(lo, hi), ...]: the element ranges (inside one rank's block) of the pieces in which the input of K xbar (0) / K'y (1) travels"""
+        plan = self._plans.get(int(transpose))
+        if plan is None:
+            nc, b = C.c_int32(0), (C.c_int64 * 5)()
+            N.check(self.lib.pdlp_exchange_plan(self.h, int(transpose), C.byref(nc), b), "pdlp_exchange_plan")
+            plan = self._plans[int(transpose)] = [(int(b[c]), int(b[c + 1])) for c in range(nc.value)]
+        return plan
+
+    def _exchange(self, transpose: int, full: torch.Tensor):
+        """the input of the next product to every rank, in the pieces of its plan; the panels a piece completes are multiplied as
+        soon as it is there (all but the last piece's: those belong to the half-step that follows)"""
+        plan = self.exchange_plan(transpose)
+        if len(plan) == 1:
+            self.comm.all_gather(full)
+            return
+        works = [self.comm.all_gather_piece(full, lo, hi) for lo, hi in plan]
+        for c, w in enumerate(works):
+            if w is not None:
+                w.wait()
+            if c + 1 < len(works):
+                N.check(self.lib.pdlp_half_chunk(self.h, int(transpose), c), "pdlp_half_chunk")
+
     def split_info(self, transpose: int) -> dict:
         """how a sharded product is split so that its local panels overlap the all-gather (zeros: not split)"""
         out = (C.c_int32 * 4)()
@@ -495,11 +548,14 @@ class PdlpEngine:
             # the panels of K that meet this rank's own block of xbar are multiplied (side stream) while the
             # other blocks are still on the wire; the same for K' and y below
             N.check(lib.pdlp_dual_half_begin(h, a), "pdlp_dual_half_begin")
-            comm.all_gather(xbar)                          # K xbar needs every rank's block of xbar
+            self._exchange(0, xbar)                        # K xbar needs every rank's block of xbar
             N.check(lib.pdlp_dual_half(h, a), "pdlp_dual_half")
+            ynew = gdy if self.delta else self.buffer(N.BUF_Y_CUR)      # the next K'y needs every rank's block of y (buffers alternate)
             if it + 1 < iters:                             # (the new y is final: a rejected adaptive step is kept, quirk Q1)
                 N.check(lib.pdlp_primal_half_begin(h), "pdlp_primal_half_begin")
-            comm.all_gather(gdy if self.delta else self.buffer(N.BUF_Y_CUR))   # the next K'y needs every rank's block of y (buffers alternate)
+                self._exchange(1, ynew)
+            else:
+                comm.all_gather(ynew)
             if adaptive:
                 N.check(lib.pdlp_adaptive_reduce(h), "pdlp_adaptive_reduce")
                 comm.all_reduce_sum(red)

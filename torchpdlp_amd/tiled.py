@@ -106,9 +106,9 @@ def rowsum_groups(rows: int) -> int:
     """panel groups the library's row-sum scratch has room for on a handle whose longer local side has ``rows`` rows
     (``rowsum_groups`` in csrc/pdlp_hip.hip; ``pdlp_tile_limits`` reports the same number for a live handle): splitting a
     row block's panels over several workgroups only pays while one workgroup per row block cannot fill 2 x 256 CUs"""
-    if rows <= NT * RPT_MAX * 128:
-        return 16
-    return 8 if rows <= NT * RPT_MAX * 512 else 1
+    if rows <= NT * 40 * 128:
+        return 24               # (small shards: the local panels' groups plus those of every chunk of a chunked exchange)
+    return 8 if rows <= NT * 40 * 512 else 1
 
 
 def _wrap_i32(v: torch.Tensor) -> torch.Tensor:
