@@ -105,6 +105,9 @@ def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=None, help="ranks (= GPUs); default: WORLD_SIZE of the launcher, else 1")
     p.add_argument("--ruiz", action="store_true", help="BASELINE configs[4]: Ruiz-precondition the LP first (sharded sweeps when N > 1)")
+    p.add_argument("--exchange-chunks", default="auto",
+                   help="N > 1: pieces in which a gathered vector travels (1..4), or auto: time this machine's all-gather against a "
+                        "rank's product and use 2 pieces when the all-gather is more than half a product long")
     p.add_argument("--lib-comm", choices=["auto", "off"], default="auto",
                    help="N > 1 under RCCL: try the exchange inside the library (cross-checked against the torch.distributed loop, "
                         "falls back on any difference) or stay on the torch.distributed loop")
@@ -375,6 +378,11 @@ def main(argv=None):
         # which code drives the exchange between the half-steps: the library's own RCCL communicator (one C call per restart
         # period) if every rank can set it up AND its iterations equal the torch.distributed loop's bit for bit; else that loop
         exchange = {"path": "torch.distributed loop", "backend": comm.backend, "ranks": comm.world}
+        if args.exchange_chunks == "auto":
+            exchange["pieces"] = eng.tune_exchange_chunks()
+        else:
+            eng.set_exchange_chunks(int(args.exchange_chunks))
+            exchange["pieces"] = {"chunks": int(args.exchange_chunks)}
         if args.lib_comm == "auto" and comm.backend == "nccl":
             on = eng.enable_library_comm(timeout=float(os.environ.get("PDLP_COMM_TIMEOUT", "90")), cross_check=True)
             exchange["path"] = "library RCCL communicator (pdlp_iterate)" if on else "torch.distributed loop (library path declined)"

@@ -431,6 +431,45 @@ class PdlpEngine:
         self.xchunks = int(chunks)
         self._plans = {}
 
+    def tune_exchange_chunks(self, reps: int = 4) -> dict:
+        """Choose the number of pieces from what THIS machine does: time the all-gather of one gathered vector and this rank's
+        product with K (max over the ranks).  Measured with stand-ins on one GPU (profiles/r03_split_chunks.log): one piece wins
+        while the all-gather takes less than about half a product (the extra launches and partial-sum slots of a chunked exchange
+        cost more than the overlap gains), two pieces win beyond that (-7 % at 8 ranks with a 0.2 ms all-gather, -12 % at 4 ranks
+        with 0.3 ms).  Collective: every rank calls it; all end up with the same choice."""
+        out = dict(chunks=1, all_gather_ms=None, product_ms=None)
+        if self.comm is None or self.tiles[0] is None or self.split_info(0)["local_groups"] == 0:
+            return out
+        full = self.buffer(N.BUF_GDX if self.delta else N.BUF_XBAR)
+        vin = torch.zeros(self.n, dtype=self.dtype, device=self.device)
+        res = torch.empty(self.ml, dtype=self.dtype, device=self.device)
+        ev = lambda: torch.cuda.Event(enable_timing=True)
+
+        def timed(fn):
+            fn()
+            self.stream.synchronize()
+            a, b = ev(), ev()
+            a.record(self.stream)
+            for _ in range(reps):
+                fn()
+            b.record(self.stream)
+            b.synchronize()
+            return a.elapsed_time(b) / reps
+        self.comm.dist.barrier(group=self.comm.group)
+        ag = timed(lambda: self.comm.all_gather(full))
+        prod = timed(lambda: N.check(self.lib.pdlp_spmv(self.h, 0, vin.data_ptr(), res.data_ptr()), "pdlp_spmv"))
+        t = torch.tensor([ag, prod], dtype=torch.float64, device=self.device)
+        self.comm.all_reduce_max(t)
+        ag, prod = float(t[0]), float(t[1])
+        chunks = 2 if ag > 0.5 * prod else 1
+        self.set_exchange_chunks(chunks)
+        if chunks > 1 and any(len(self.exchange_plan(tr)) != chunks for tr in (0, 1) if self.tiles[tr] is not None):
+            chunks = 1                        # (too few panels for pieces on some matrix: stay with one all-gather)
+            self.set_exchange_chunks(1)
+        full.zero_()
+        out.update(chunks=chunks, all_gather_ms=round(ag, 4), product_ms=round(prod, 4))
+        return out
+
     def exchange_plan(self, transpose: int) -> list:
         """[(lo, hi), ...]: the element ranges (inside one rank's block) of the pieces in which the input of K xbar (0) / K'y (1) travels"""
         plan = self._plans.get(int(transpose))
