@@ -36,7 +36,12 @@ struct FakeComm {
 };
 
 constexpr size_t HDR_BYTES = 4096;
-constexpr double TIMEOUT_S = 120.0;
+double timeout_s()
+{
+    static const double t = std::getenv("PDLP_FAKE_RCCL_TIMEOUT") ? std::atof(std::getenv("PDLP_FAKE_RCCL_TIMEOUT")) : 60.0;
+    return t;
+}
+#define TIMEOUT_S (timeout_s())
 
 size_t data_capacity()
 {

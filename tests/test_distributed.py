@@ -497,6 +497,9 @@ def _libcomm_worker(rank, world, port, ret, tiled):
         configs = [("f32", torch.float32, None, False), ("f64", torch.float64, None, False), ("mixed", torch.float32, torch.float64, False)]
         if not tiled:
             configs.append(("mixed+exact", torch.float64, torch.float64, True))
+        elif world > 2:          # (ranks sharing one card take turns on it: every synchronisation costs a time slice)
+            configs = [configs[0], configs[2]]
+        n1, n2 = (9, 4) if not tiled else (3, 2)
         for name, mat_dt, vec_dt, exact in configs:
             vd = vec_dt or mat_dt
             val = lp.val + rough if exact else lp.val
@@ -513,7 +516,9 @@ def _libcomm_worker(rank, world, port, ret, tiled):
             if tiled:
                 assert all(t is not None for t in eB.tiles) and eB.split_info(0)["local_groups"] >= 1
             whole = {}
-            for chunks in ((1, 2, 3) if tiled else (1,)):
+            trace = (lambda *a: print(f"[rank {rank}]", *a, flush=True)) if os.environ.get("PDLP_TEST_TRACE") else (lambda *a: None)
+            for chunks in (((1, 2, 3) if (world == 2 and name == "f32") else (1, 2)) if tiled else (1,)):
+                trace(name, "chunks", chunks)
                 # chunked exchange (tiled products only): the gathered vector travels in `chunks` pieces and the panels a piece
                 # completes are multiplied while the next piece is on the wire -- again the same bits on both drivers, and the
                 # same numbers as the one-piece exchange up to the grouping of the partial row sums
@@ -530,10 +535,11 @@ def _libcomm_worker(rank, world, port, ret, tiled):
                 for adaptive in (True, False):
                     outs = []
                     for e in (eA, eB):
+                        trace(name, chunks, "adaptive" if adaptive else "fixed", "library driver" if e is eB else "torch loop")
                         e.set_iterate(e.part.pad_cols(x0.to(vd))[e.cols[0]:e.cols[1]], e.part.pad_rows(y0.to(vd))[e.rows[0]:e.rows[1]])
                         e.set_step(0.02, 1.1, 1.0, 0)
-                        e.iterate(9, adaptive)
-                        e.iterate(4, adaptive)
+                        e.iterate(n1, adaptive)
+                        e.iterate(n2, adaptive)
                         x, y = e.get_iterate(N.CUR)
                         outs.append((x.clone(), y.clone(), e.scalars()["eta"], e.kkt(N.CUR, 1.0)["kkt"]))
                     (xa, ya, ea, ka), (xb, yb, eb, kb) = outs

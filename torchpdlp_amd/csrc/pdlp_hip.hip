@@ -575,6 +575,18 @@ template <typename T> void kkt_finish_t(const double* r, double omega_d, double*
     out[0] = pr; out[1] = dr; out[2] = gap; out[3] = p; out[4] = adj; out[5] = kkt;
 }
 
+// The pieces of a chunked exchange: piece c moves elements [sb[c], sb[c+1]) of every rank's block of `B` elements (multiples of
+// 64 elements: 256-byte pieces).  A function of B and the requested count alone -- every rank computes the same plan, whether
+// or not its own product is split (the collectives must match on all ranks; what a rank multiplies early is its own business).
+int plan_bounds(int64_t B, int xchunks, int64_t* sb /*[MAX_PHASE]*/)
+{
+    int C = xchunks < 1 ? 1 : (xchunks > MAX_CHUNKS ? MAX_CHUNKS : xchunks);
+    if (B < (int64_t)64 * C) C = 1;
+    for (int c = 0; c <= C; ++c) sb[c] = c == C ? B : (c * B / C) / 64 * 64;
+    for (int c = C + 1; c < MAX_PHASE; ++c) sb[c] = B;
+    return C;
+}
+
 // panel groups of the split product of one matrix (see Schedule): which panels belong to which phase of the exchange, and how
 // many workgroup groups (= partial row sum slots) every phase gets
 int configure_split(pdlp_handle h, bool transpose)
@@ -592,10 +604,7 @@ int configure_split(pdlp_handle h, bool transpose)
     const int pa = (int)((lo + W - 1) / W), pb = hi == total ? npanel : (int)(hi / W);
     const int nloc = pb - pa, nrem = npanel - nloc;
     if (nloc <= 0 || nrem <= 0 || h->rs_groups < 2 || !s.ptab || npanel > s.ptab_cap || B <= 0 || lo % B != 0) return PDLP_OK;
-    // chunk c of the exchange moves elements [sb[c], sb[c+1]) of every rank's block (multiples of 64 elements: 256-byte pieces)
-    int C = h->xchunks < 1 ? 1 : (h->xchunks > MAX_CHUNKS ? MAX_CHUNKS : h->xchunks);
-    if (B < (int64_t)64 * C) C = 1;
-    for (int c = 0; c <= C; ++c) s.sb[c] = c == C ? B : (c * B / C) / 64 * 64;
+    const int C = plan_bounds(B, h->xchunks, s.sb);
     // a panel is complete once the last of its foreign entries has arrived
     std::vector<int> phase((size_t)npanel);
     int cnt[MAX_PHASE] = {0};
@@ -1462,16 +1471,11 @@ int pdlp_set_exchange_chunks(pdlp_handle h, int chunks)
 int pdlp_exchange_plan(pdlp_handle h, int transpose, int32_t* nchunks, int64_t bounds[5])
 {
     if (!h || !nchunks || !bounds) return PDLP_ERR_INVALID;
-    const Schedule& s = transpose ? h->sKT : h->sK;
-    const int64_t B = transpose ? h->ml : h->nl;
-    if (s.nphase == 0) {                          // the product is not split: one exchange of the whole block
-        *nchunks = 1;
-        bounds[0] = 0; bounds[1] = B;
-        for (int c = 2; c < 5; ++c) bounds[c] = B;
-        return PDLP_OK;
-    }
-    *nchunks = s.nphase - 1;
-    for (int c = 0; c < 5; ++c) bounds[c] = c < s.nphase ? s.sb[c] : B;
+    // (a function of the block length and the requested count only: the same on every rank, whether or not this rank's own
+    // product is split -- the pieces are collectives)
+    int64_t sb[MAX_PHASE];
+    *nchunks = plan_bounds(transpose ? h->ml : h->nl, h->xchunks, sb);
+    for (int c = 0; c < 5; ++c) bounds[c] = sb[c];
     return PDLP_OK;
 }
 
@@ -1593,14 +1597,13 @@ int comm_all_gather(pdlp_handle h, void* full, int64_t count, bool f32)
 
 // the exchange of one gathered vector in the chunks of its product's plan: chunk c = elements [sb[c], sb[c+1]) of every rank's
 // block, as one group of in-place broadcasts (one root per rank) on the communication stream; ev_chunk[c] marks its arrival
-int comm_exchange_chunked(pdlp_handle h, const Schedule& s, void* full, int64_t block, bool f32)
+int comm_exchange_chunked(pdlp_handle h, int C, const int64_t* sb, void* full, int64_t block, bool f32)
 {
     const size_t esz = f32 ? 4 : 8;
-    const int C = s.nphase - 1;
     HIP_TRY(hipEventRecord(h->ev_vec, h->stream));               // this rank's block is final
     HIP_TRY(hipStreamWaitEvent(h->cstream, h->ev_vec, 0));
     for (int c = 0; c < C; ++c) {
-        const int64_t lo = s.sb[c], cnt = s.sb[c + 1] - s.sb[c];
+        const int64_t lo = sb[c], cnt = sb[c + 1] - sb[c];
         if (cnt > 0) {
             RCCL_TRY(g_rccl.GroupStart());
             for (int q = 0; q < h->comm_size; ++q) {
@@ -1622,16 +1625,17 @@ int sharded_exchange_and_begin(pdlp_handle h, bool transpose, int adaptive, bool
 {
     int rc;
     const bool vec32 = h->p.dtype == PDLP_F32;
-    const Schedule& s = transpose ? h->sKT : h->sK;
     void* full = transpose ? (h->delta ? (void*)h->gdy : (void*)h->yb[h->ix_cur]) : (h->delta ? (void*)h->gdx : (void*)h->xbar);
     const int64_t block = transpose ? h->ml : h->nl;
     const bool f32 = h->delta || vec32;
     // the panels that meet this rank's own block are multiplied (side stream) while the other blocks are on the wire
     if (begin && (rc = (transpose ? pdlp_primal_half_begin(h) : pdlp_dual_half_begin(h, adaptive))) != PDLP_OK) return rc;
-    const bool chunked = s.pending && s.nphase > 2 && h->cstream && g_rccl.Broadcast && g_rccl.GroupStart && g_rccl.GroupEnd;
+    // (the shape of the exchange must not depend on anything rank local -- every rank issues the same collectives)
+    int64_t sb[MAX_PHASE];
+    const int C = plan_bounds(block, h->xchunks, sb);
+    const bool chunked = C > 1 && h->cstream && g_rccl.Broadcast && g_rccl.GroupStart && g_rccl.GroupEnd;
     if (!chunked) return comm_all_gather(h, full, block, f32);
-    if ((rc = comm_exchange_chunked(h, s, full, block, f32)) != PDLP_OK) return rc;
-    const int C = s.nphase - 1;
+    if ((rc = comm_exchange_chunked(h, C, sb, full, block, f32)) != PDLP_OK) return rc;
     for (int c = 0; c + 1 < C; ++c) {
         HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_chunk[c], 0));
         if ((rc = pdlp_half_chunk(h, transpose ? 1 : 0, c)) != PDLP_OK) return rc;

@@ -592,9 +592,7 @@ class PdlpEngine:
             ynew = gdy if self.delta else self.buffer(N.BUF_Y_CUR)      # the next K'y needs every rank's block of y (buffers alternate)
             if it + 1 < iters:                             # (the new y is final: a rejected adaptive step is kept, quirk Q1)
                 N.check(lib.pdlp_primal_half_begin(h), "pdlp_primal_half_begin")
-                self._exchange(1, ynew)
-            else:
-                comm.all_gather(ynew)
+            self._exchange(1, ynew)                        # (no product under way after the last iteration: the pieces just arrive)
             if adaptive:
                 N.check(lib.pdlp_adaptive_reduce(h), "pdlp_adaptive_reduce")
                 comm.all_reduce_sum(red)
