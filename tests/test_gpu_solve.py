@@ -295,3 +295,37 @@ def test_user_supplied_instances(path):
                   A_eq=A[m_ineq:] if m_ineq < K.m else None, b_eq=qn[m_ineq:] if m_ineq < K.m else None, bounds=bounds, method="highs")
     assert ref.status == 0, ref.message
     assert abs(res.objective - ref.fun) <= 2e-3 * (1 + abs(ref.fun)), (res.objective, ref.fun)
+
+
+def test_cli_sharded_over_two_ranks(tmp_path):
+    """The batch driver under a launcher (main.py:83-172 over two ranks that share this box's GPU, collectives over gloo): every rank
+    parses on the host and holds only its blocks; rank 0 writes the reference's CSV.  A file that fails on every rank alike (it does
+    not load) gets its row and the loop goes on (the sharded run used to leave at the first failure)."""
+    import shutil
+    import socket
+    import subprocess
+    import sys
+    inst = tmp_path / "inst"
+    inst.mkdir()
+    for f in ("afiro.mps", "all_eq.mps", "marker.mps"):          # marker.mps: integer MARKER lines make the load fail (reference quirk)
+        shutil.copy(os.path.join(MPS_DIR, f), inst / f)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   PDLP_SHARE_GPU="1", PDLP_DIST_BACKEND="gloo", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        procs.append(subprocess.Popen([sys.executable, "-m", "torchpdlp_amd", "--instance_path", str(inst), "--output_path", str(tmp_path / "out"),
+                                       "--adaptive_stepsize", "--primal_weight_update", "--precondition", "--seed", "3"],
+                                      env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], outs
+    rows = list(csv.DictReader(open(tmp_path / "out" / "solver_results.csv")))
+    by = {r["File"]: r for r in rows}
+    assert sorted(by) == ["afiro.mps", "all_eq.mps", "marker.mps"]
+    assert by["afiro.mps"]["Status"] == "Solved" and abs(float(by["afiro.mps"]["Objective"]) - AFIRO_OPT) < 0.5
+    assert by["all_eq.mps"]["Status"] == "Solved"
+    assert by["marker.mps"]["Objective"] == "N/A"                 # the failure row, and the run went on past it
+    assert "x 2 ranks" in outs[0]
