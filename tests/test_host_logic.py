@@ -233,3 +233,18 @@ def test_bench_command_line_contract(monkeypatch):
     assert rec["n10000000_k100"]["1e-8"]["seconds"] < 1200            # inside one GPU call of this pool
     tr = json.load(open(os.path.join(root, "profiles", "traffic.json")))
     assert set(tr["n10000000_k100_f32_adaptive_g1_tiled"]) >= {"primal", "dual"}
+
+
+def test_one_handle_is_limited_to_int32_offsets_and_says_so():
+    """row pointers, tile offsets and schedule entries are int32, so one handle (= one rank) holds fewer than 2^31
+    non-zeros per matrix copy.  The bound is a hard, explicit error -- not a wrap-around -- and names the remedy."""
+    import pytest, torch
+    from torchpdlp_amd.sparse import _counts_to_rowptr
+    ok = _counts_to_rowptr(torch.tensor([2 ** 30, 2 ** 30 - 1], dtype=torch.int64))
+    assert ok.dtype == torch.int32 and int(ok[-1]) == 2 ** 31 - 1
+    with pytest.raises(ValueError, match=r"2\^31-1 non-zeros in one shard: split the problem across more ranks"):
+        _counts_to_rowptr(torch.tensor([2 ** 30, 2 ** 30], dtype=torch.int64))
+    # the tile builder declines (None -> the CSR kernel stays) before any 32-bit item offset could overflow
+    from torchpdlp_amd import tiled as T
+    import inspect
+    assert "2 ** 31" in inspect.getsource(T.build_tiles)
