@@ -383,7 +383,11 @@ def main(argv=None):
         else:
             eng.set_exchange_chunks(int(args.exchange_chunks))
             exchange["pieces"] = {"chunks": int(args.exchange_chunks)}
-        if args.lib_comm == "auto" and comm.backend == "nccl":
+        if args.lib_comm == "auto" and comm.backend == "nccl" and eng.xchunks > 1:
+            # (a chunked exchange stays on torch.distributed's own collectives here: the library's form of it -- grouped broadcasts
+            # on a second stream -- has only ever run against the test stand-in, and a first contact belongs outside a benchmark)
+            exchange["path"] = "torch.distributed loop (chunked exchange: library driver not tried)"
+        elif args.lib_comm == "auto" and comm.backend == "nccl":
             on = eng.enable_library_comm(timeout=float(os.environ.get("PDLP_COMM_TIMEOUT", "90")), cross_check=True)
             exchange["path"] = "library RCCL communicator (pdlp_iterate)" if on else "torch.distributed loop (library path declined)"
             exchange["log"] = eng.lib_comm_log
