@@ -7,6 +7,11 @@
 #   round2 / round1  gather rounds of 2 / of 1 per lane instead of 4
 #   cnttop        count words loaded at the top of their tile    csrbranchy conditional loads in the CSR kernel
 #   nogather / stamps   ablation (wrong results) / cycle stamps per phase, both diagnostic only
+# round 3 (profiles/r03_ab*.log):
+#   abl_noval / abl_nocounts   no value stream / count words loaded once per workgroup (wrong results, timing only)
+#   cnt_thread_major           the count-word layout of rounds 1-2 (time it with "lib.so:PDLP_CNT_LAYOUT=thread" in ab_kernels.py)
+#   slide1 / slide2            8 / 12 gathers per lane in flight (sliding window)
+#   nt_gather, stagger_200     gathers bypassing L1; the second workgroup of a CU starts 200 x 64 clocks late
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/_bin
@@ -24,6 +29,15 @@ build csrbranchy -DPDLP_CSR_BRANCHY &
 wait
 build nogather -DPDLP_ABL_NOGATHER &
 build stamps -DPDLP_STAMPS &
+wait
+build abl_noval -DPDLP_ABL_NOVAL &
+build abl_nocounts -DPDLP_ABL_NOCOUNTS &
+build cnt_thread_major -DPDLP_COUNTS_THREAD_MAJOR &
+build slide1 -DPDLP_SLIDE=1 &
+wait
+build slide2 -DPDLP_SLIDE=2 &
+build nt_gather -DPDLP_NT_GATHER &
+build stagger_200 -DPDLP_STAGGER=200 &
 wait
 rm -f tools/_bin/*.hipfb
 ls tools/_bin
