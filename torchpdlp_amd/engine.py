@@ -61,7 +61,9 @@ class Comm:
                 if q != self.rank:
                     views[q].copy_(part)
             return None
-        return self.dist.all_gather(views, views[self.rank], group=self.group, async_op=True)
+        # (the input is a copy of this rank's piece: an output list that aliases the input is not something to try for the first
+        # time inside a timed run; the copy is 1/world of a piece)
+        return self.dist.all_gather(views, views[self.rank].clone(), group=self.group, async_op=True)
 
     def all_reduce_sum(self, t: torch.Tensor, op=None):
         op = self.dist.ReduceOp.SUM if op is None else op
