@@ -317,6 +317,12 @@ int pdlp_spmv(pdlp_handle h, int transpose, const void* in_full, void* out_local
 /* spectral_norm_estimate_torch helpers.py:41-51 with the start vector given (single rank) */
 int pdlp_power_iteration(pdlp_handle h, const void* b0, int iters, void* work_n, void* work_m, double* sigma);
 
+/* Measurement aid (no counterpart in the reference): GB/s at which this GPU streams `bytes` (>= 16 MiB, 16-byte aligned, zero
+ * filled) with the tiled kernel's access pattern -- 512 workgroups, each its own contiguous slice, four 16-byte non-temporal loads
+ * in flight per thread; one warm-up launch, then `reps` timed ones (HIP events on `stream`).  bench.py reports it beside the
+ * nominal 8 TB/s as `roofline.measured_read_ceiling`. */
+int pdlp_probe_stream_read(const void* buf, int64_t bytes, int reps, void* stream, double* gb_per_s);
+
 /* ---- Ruiz equilibration on CSR (ruiz_precondition enhancements.py:4-71) ---------------------- */
 /* norm[i] = sqrt(max_p |val[p]|) over row i, replaced by 1 when < eps (:49-50 / :54-55) */
 int pdlp_csr_row_scale_factors(int dtype, int64_t rows, const int32_t* rowptr, const void* val, double eps,

@@ -385,6 +385,11 @@ def _rccl_world1_worker(rank, world, port, ret):
         red = torch.ones(8, dtype=torch.float64, device=dev)
         comm.all_reduce_sum(red)
         assert torch.equal(full.cpu(), torch.arange(12, dtype=torch.float32)) and float(red.sum()) == 8.0
+        work = comm.all_gather_piece(full, 2, 6)            # a piece of a chunked exchange: asynchronous list all-gather under RCCL
+        assert work is not None
+        work.wait()
+        torch.cuda.current_stream().synchronize()
+        assert torch.equal(full.cpu(), torch.arange(12, dtype=torch.float32)) and comm.all_gather_piece(full, 4, 4) is None
         for dtype, kw in ((torch.float32, {}), (torch.float64, {}), (torch.float32, dict(vec_dtype=torch.float64))):
             lp = gen_lp(40_000, 30_000, 6, seed=3, device=dev, recipe="mixed", dtype=torch.float64)
             K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val.to(dtype))

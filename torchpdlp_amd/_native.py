@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PDLP_LIB", os.path.join(_HERE, "libpdlp_hip.so"))   # PDLP_LIB: profiling/ablation builds
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 PDLP_F32, PDLP_F64, PDLP_MIXED = 0, 1, 2
 CUR, AVG, PREV = 0, 1, 2
 (BUF_X_CUR, BUF_X_PREV, BUF_XBAR, BUF_X_AVG, BUF_Y_CUR, BUF_Y_PREV, BUF_Y_AVG, BUF_RED, BUF_X_SUM, BUF_Y_SUM,
@@ -96,6 +96,7 @@ SIGNATURES = {
     "pdlp_mv_gap": (_I, [_H, _I, _P, _P, _P, C.POINTER(_D)]),
     "pdlp_spmv": (_I, [_H, _I, _P, _P]),
     "pdlp_power_iteration": (_I, [_H, _P, _I, _P, _P, C.POINTER(_D)]),
+    "pdlp_probe_stream_read": (_I, [_P, _I64, _I, _P, C.POINTER(_D)]),
     "pdlp_csr_row_scale_factors": (_I, [_I, _I64, _P, _P, _D, _P, _P]),
     "pdlp_csr_div_rows": (_I, [_I, _I64, _P, _P, _P, _P]),
     "pdlp_csr_div_cols": (_I, [_I, _I64, _P, _P, _P, _P]),

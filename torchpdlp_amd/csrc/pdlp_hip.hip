@@ -1140,7 +1140,7 @@ int read_last_rowptr(const int32_t* rp, int64_t rows, int64_t* nnz, hipStream_t 
 // ================================================================================================
 extern "C" {
 
-int pdlp_abi_version(void) { return 13; }  // 13: chunked exchange (pdlp_set_exchange_chunks, pdlp_exchange_plan, pdlp_half_chunk); 12: count words of a tile laid out for coalesced loads; 11: pdlp_comm_load; 10: pdlp_set_anchors; 9: pdlp_attach_sorted; 8: running products, pdlp_flush_average(h, adaptive); 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
+int pdlp_abi_version(void) { return 14; }  // 14: pdlp_probe_stream_read; 13: chunked exchange (pdlp_set_exchange_chunks, pdlp_exchange_plan, pdlp_half_chunk); 12: count words of a tile laid out for coalesced loads; 11: pdlp_comm_load; 10: pdlp_set_anchors; 9: pdlp_attach_sorted; 8: running products, pdlp_flush_average(h, adaptive); 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
 
 const char* pdlp_strerror(int code)
 {
@@ -1966,6 +1966,30 @@ int pdlp_delta_state(pdlp_handle h, int32_t out[3])
 {
     if (!h || !out) return PDLP_ERR_INVALID;
     out[0] = h->delta; out[1] = h->anchors_valid; out[2] = h->dy_folded;
+    return PDLP_OK;
+}
+
+int pdlp_probe_stream_read(const void* buf, int64_t bytes, int reps, void* stream, double* gb_per_s)
+{
+    if (!buf || bytes < ((int64_t)1 << 24) || reps < 1 || !gb_per_s || ((uintptr_t)buf & 15u)) return PDLP_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n16 = (size_t)bytes / 16;
+    const int grid = 512;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    unsigned* sink = (unsigned*)const_cast<void*>(buf);           // (never written: see the kernel)
+    hipLaunchKernelGGL(k_probe_read, dim3(grid), dim3(512), 0, s, (const probe_u32x4*)buf, n16, sink);
+    HIP_TRY(hipEventRecord(e0, s));
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_probe_read, dim3(grid), dim3(512), 0, s, (const probe_u32x4*)buf, n16, sink);
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    HIP_TRY(hipGetLastError());
+    const size_t per = n16 / grid, read16 = per / (4 * 512) * (4 * 512) * grid;      // what the kernel really loads
+    *gb_per_s = (double)read16 * 16.0 * reps / ((double)ms * 1e-3) / 1e9;
     return PDLP_OK;
 }
 
