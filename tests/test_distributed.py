@@ -105,6 +105,16 @@ def _cpu_worker(rank, world, port, ret, balance="rows"):
         padx[part.col_map("cpu")] = False
         pady[part.row_map("cpu")] = False
         assert float(x[padx].abs().sum()) == 0 and float(y[pady].abs().sum()) == 0           # padding stays at 0
+        # the chunked exchange's transport: pieces = the same slice of every rank's block, asynchronous, in order
+        B = 1000
+        full = torch.zeros(world * B)
+        full[rank * B:(rank + 1) * B] = torch.arange(B, dtype=torch.float32) + 10_000 * (rank + 1)
+        works = [comm.all_gather_piece(full, lo, hi) for lo, hi in ((0, 448), (448, 1000))]
+        for w in works:
+            if w is not None:
+                w.wait()
+        want = torch.cat([torch.arange(B, dtype=torch.float32) + 10_000 * (q + 1) for q in range(world)])
+        assert torch.equal(full, want) and comm.all_gather_piece(full, 5, 5) is None
         # an 8-double all-reduce like the KKT partial sums
         red = torch.tensor([float(rank + 1)] * 8, dtype=torch.float64)
         comm.all_reduce_sum(red)
