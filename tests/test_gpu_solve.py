@@ -329,3 +329,23 @@ def test_cli_sharded_over_two_ranks(tmp_path):
     assert by["all_eq.mps"]["Status"] == "Solved"
     assert by["marker.mps"]["Objective"] == "N/A"                 # the failure row, and the run went on past it
     assert "x 2 ranks" in outs[0]
+
+
+def test_mixed_precision_with_ruiz_on_a_plus_minus_one_matrix():
+    """Ruiz on a matrix of +-1 entries is the identity, so the scaled matrix IS float32-valued and needs no separate exact
+    matrix -- `--dtype mixed --precondition` on such an LP (set cover, network LPs) used to be refused with a ValueError."""
+    from torchpdlp_amd.synthetic import gen_lp
+    lp = gen_lp(301, 403, 4, seed=21, recipe="mixed", ineq_frac=0.6, device="cuda:0", dtype=torch.float64)
+    K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, torch.sign(lp.val) + (lp.val == 0))
+    x_f = lp.x_feas.double()
+    rows = torch.repeat_interleave(torch.arange(lp.m, device="cuda:0"), (lp.rowptr[1:] - lp.rowptr[:-1]).long())
+    kx = torch.zeros(lp.m, dtype=torch.float64, device="cuda:0").index_add_(0, rows, K.val * x_f[lp.colidx.long()])
+    q = kx.clone()
+    q[:lp.m_ineq] -= 0.5                                        # x_feas stays feasible: the LP is feasible and (boxed or not) solvable
+    res = tp.solve_lp((lp.c, K, q, lp.m_ineq, torch.maximum(lp.l, x_f - 5), torch.minimum(lp.u, x_f + 5)), tol=1e-6, precondition=True,
+                      primal_weight_update=True, adaptive_stepsize=True, seed=1, precision="mixed", max_kkt=2_000_000)
+    assert res.status == "Solved", res.status
+    xs = res.x.view(-1).double()
+    r = torch.zeros(lp.m, dtype=torch.float64, device="cuda:0").index_add_(0, rows, K.val * xs[lp.colidx.long()]) - q
+    r[:lp.m_ineq].clamp_(max=0)
+    assert float(r.norm()) <= 2e-6 * (1 + float(q.norm()))
