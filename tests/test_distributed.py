@@ -636,7 +636,7 @@ def _ruiz_worker(rank, world, port, ret):
                 for key in ("c", "q", "l", "u", "d_col", "d_row"):
                     assert torch.equal(got[key], want[key]), (case, balance, key)
         # a generated instance that exists only as shards: (a) against the single-process Ruiz of the whole instance
-        n, m, k = 70_001, 131_075, 6
+        n, m, k = 1_000_003, 2_000_001, 6       # (2M constraints, sizes that divide by no world size: padded blocks)
         sh = gen_lp_shard_arrays(n, m, k, 9, comm, dev, torch.float64)
         got = ruiz_precondition_shard({kk: v for kk, v in sh.items() if kk not in ("part", "nnz_local")}, comm)
         lp = gen_lp(n, m, k, seed=9, device=dev, dtype=torch.float64)
