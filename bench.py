@@ -41,16 +41,34 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
-def spawn_ranks(gpus: int, argv, script: str = None, env: dict = None) -> int:
+def spawn_ranks(gpus: int, argv, script: str = None, env: dict = None, launch_timeout: float = None, grace: float = None) -> int:
     """Start `gpus` rank processes of `script` (this file) as CHILD processes -- one per GPU, each with the launcher environment
     torch.distributed expects (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR=127.0.0.1, MASTER_PORT) --, pass rank 0's JSON line
-    through and return the exit code: 0 only if every rank finished and a line came back.  The caller has not touched the GPU
-    yet, and nothing is exec'ed: the parent stays a plain Python process that waits.  (Not torch.distributed.run: its argument
-    parser claims abbreviations such as --n or --m of the script's own flags.)  If a rank fails the others are stopped."""
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    through and return the exit code.  The caller has not touched the GPU yet, and nothing is exec'ed: the parent stays a plain
+    Python process that waits.  (Not torch.distributed.run: its argument parser claims abbreviations such as --n or --m of the
+    script's own flags.)
+
+    * The rendezvous store lives in THIS process (a TCPStore on a port the OS picks while the socket stays open; the ranks join it
+      as clients, TORCHELASTIC_USE_AGENT_STORE like torch's own launcher): no window in which another process can take the port.
+    * If a rank fails the others are stopped and the job fails -- unless rank 0's result line has already arrived: a measured
+      line is never thrown away because a later, optional phase (or the teardown of a communicator) went wrong.
+    * Watchdog: once the result line is there the ranks get `grace` seconds (PDLP_BENCH_GRACE, 120) to leave by themselves, then
+      they are terminated and the line is relayed, exit 0.  Without a line the job is stopped after `launch_timeout` seconds
+      (PDLP_BENCH_LAUNCH_TIMEOUT, 3300) and fails.  The wait loop can therefore never hold a pool slot forever."""
+    launch_timeout = float(os.environ.get("PDLP_BENCH_LAUNCH_TIMEOUT", "3300")) if launch_timeout is None else float(launch_timeout)
+    grace = float(os.environ.get("PDLP_BENCH_GRACE", "120")) if grace is None else float(grace)
     base = dict(os.environ if env is None else env)
+    store = None
+    try:                                                         # (importing torch.distributed initialises no GPU)
+        from torch.distributed import TCPStore
+        store = TCPStore("127.0.0.1", 0, int(gpus), True, wait_for_workers=False)
+        port = store.port
+        base["TORCHELASTIC_USE_AGENT_STORE"] = "True"
+    except Exception as ex:                                      # no torch here (tests of the launcher alone): a free port, the old way
+        print(f"bench.py: launcher-hosted store unavailable ({type(ex).__name__}); falling back to a probed port", file=sys.stderr)
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC (RCCL between processes on this host driver)
     base.setdefault("OMP_NUM_THREADS", "4")
     base.update(WORLD_SIZE=str(int(gpus)), LOCAL_WORLD_SIZE=str(int(gpus)), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -62,14 +80,19 @@ def spawn_ranks(gpus: int, argv, script: str = None, env: dict = None) -> int:
         procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True, env=e))
     lines = []
     import threading
+    is_result = lambda ln: ln.startswith("{") and '"metric"' in ln
+    got_line = [None]                                            # time the (latest) result line arrived
 
     def pump():
         for line in procs[0].stdout:
             lines.append(line.rstrip("\n"))
+            if is_result(lines[-1]):
+                got_line[0] = time.time()
     th = threading.Thread(target=pump, daemon=True)
     th.start()
-    rc, pending = 0, set(range(len(procs)))
-    while pending and rc == 0:
+    t_start = time.time()
+    rc, pending, why = 0, set(range(len(procs))), None
+    while pending and rc == 0 and why is None:
         for r in sorted(pending):
             code = procs[r].poll()
             if code is not None:
@@ -77,9 +100,16 @@ def spawn_ranks(gpus: int, argv, script: str = None, env: dict = None) -> int:
                 if code != 0:
                     rc = code if 0 < code < 256 else 1
                     print(f"bench.py: rank {r} of {gpus} failed (exit code {code})", file=sys.stderr)
-        if pending and rc == 0:
+        now = time.time()
+        if got_line[0] is not None and now - got_line[0] > grace:
+            why = f"ranks still running {grace:.0f} s after the result line"
+        elif got_line[0] is None and now - t_start > launch_timeout:
+            why = f"no result line after {launch_timeout:.0f} s"
+        if pending and rc == 0 and why is None:
             time.sleep(0.05)
-    for r in sorted(pending):                                    # a rank failed: stop exactly the processes started here
+    if why is not None:
+        print(f"bench.py: {why}: stopping the ranks", file=sys.stderr)
+    for r in sorted(pending):                                    # stop exactly the processes started here
         procs[r].terminate()
     for r in sorted(pending):
         try:
@@ -88,17 +118,20 @@ def spawn_ranks(gpus: int, argv, script: str = None, env: dict = None) -> int:
             procs[r].kill()
             procs[r].wait()
     th.join(timeout=10)
-    result = [ln for ln in lines if ln.startswith("{") and '"metric"' in ln]
+    del store
+    result = [ln for ln in lines if is_result(ln)]
     for ln in lines:
         if ln not in result:
             print(ln, file=sys.stderr)
+    if result:
+        if rc != 0 or why is not None:
+            print("bench.py: relaying the result line that was measured before the failure", file=sys.stderr)
+        print(result[-1], flush=True)
+        return 0
     if rc != 0:
         return rc
-    if not result:
-        print("bench.py: the ranks finished without a result line", file=sys.stderr)
-        return 1
-    print(result[-1], flush=True)
-    return 0
+    print("bench.py: " + (why or "the ranks finished without a result line"), file=sys.stderr)
+    return 1
 
 
 def parse(argv=None):
@@ -211,7 +244,10 @@ def cpu_baseline(args, sv_dtype):
     kkt_s = time.time() - t1
     per_iter = step_s + 3.0 * kkt_s / 40.0            # the reference's restart cadence
     scale = (lp.nnz / float(args.nnz_per_row * (args.m or args.n)))
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     out = dict(value=round(scale / per_iter, 4), unit="iterations/s", cores=cores, kind="port",
+               machine_cores=os.cpu_count(), cores_available_to_this_process=avail,
+               cores_cap=int(os.environ.get("PDLP_CPU_THREADS", "16")),
                sample=f"oracle (C, OpenMP, CSR + pre-transposed CSR) on gen_lp({rows}x{rows}, {args.nnz_per_row} nnz/row, seed 0): "
                       f"{iters} {args.mode} iterations at {step_s * 1e3:.1f} ms + KKT pass {kkt_s * 1e3:.1f} ms x3/40; "
                       f"rate scaled by nnz ratio {scale:.4g} to the full workload")
@@ -302,6 +338,40 @@ def measure_roofline(args, eng, dt, adaptive, world):
     return roofline
 
 
+def exchange_phases(eng, comm, roofline, ms_per_iteration, reps: int = 10) -> dict:
+    """What an iteration of a sharded run is made of, each part timed ALONE on this machine (max over ranks), so that a scaling curve
+    explains itself: the two fused products of this rank's shard, the two all-gathers (x-bar, y), the 3-double all-reduce of the
+    step-size rule -- and what the exchange adds on the critical path (iteration - products)."""
+    dev, st = eng.device, eng.stream
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+
+    def timed(fn):
+        fn()
+        st.synchronize()
+        a, b = ev(), ev()
+        a.record(st)
+        for _ in range(reps):
+            fn()
+        b.record(st)
+        b.synchronize()
+        return a.elapsed_time(b) / reps
+    fx = torch.zeros_like(eng.buffer(N.BUF_XBAR))
+    fy = torch.zeros_like(eng.buffer(N.BUF_Y_CUR))
+    red = torch.zeros(3, dtype=torch.float64, device=dev)
+    comm.dist.barrier(group=comm.group)
+    t = torch.tensor([timed(lambda: comm.all_gather(fx)), timed(lambda: comm.all_gather(fy)), timed(lambda: comm.all_reduce_sum(red))],
+                     dtype=torch.float64, device=dev)
+    comm.all_reduce_max(t)
+    product = float(roofline.get("launch_ms", 0.0)) + float(roofline.get("other_kernel_ms", 0.0))
+    tp_ = torch.tensor([product], dtype=torch.float64, device=dev)
+    comm.all_reduce_max(tp_)
+    product = float(tp_)
+    return dict(product_ms=round(product, 4), all_gather_xbar_ms=round(float(t[0]), 4), all_gather_y_ms=round(float(t[1]), 4),
+                allreduce_ms=round(float(t[2]), 4), iteration_ms=round(ms_per_iteration, 4),
+                exchange_exposed_ms=round(ms_per_iteration - product, 4),
+                note="each part timed alone (max over ranks); exposed = iteration - the two fused products")
+
+
 def _imports():
     """torch and the package, only in a process that is going to compute (after the decision to spawn ranks)"""
     global torch, tp, N, PdhgDriver, estimate_sigma
@@ -387,31 +457,12 @@ def main(argv=None):
     torch.cuda.empty_cache()
     exchange = None
     if comm is not None:
-        # which code drives the exchange between the half-steps: the library's own RCCL communicator (one C call per restart
-        # period) if every rank can set it up AND its iterations equal the torch.distributed loop's bit for bit; else that loop
         exchange = {"path": "torch.distributed loop", "backend": comm.backend, "ranks": comm.world}
         if args.exchange_chunks == "auto":
             exchange["pieces"] = eng.tune_exchange_chunks()
         else:
             eng.set_exchange_chunks(int(args.exchange_chunks))
             exchange["pieces"] = {"chunks": int(args.exchange_chunks)}
-        if args.lib_comm == "auto" and comm.backend == "nccl" and eng.xchunks > 1:
-            # (a chunked exchange stays on torch.distributed's own collectives here: the library's form of it -- grouped broadcasts
-            # on a second stream -- has only ever run against the test stand-in, and a first contact belongs outside a benchmark)
-            exchange["path"] = "torch.distributed loop (chunked exchange: library driver not tried)"
-        elif args.lib_comm == "auto" and comm.backend == "nccl":
-            on = eng.enable_library_comm(timeout=float(os.environ.get("PDLP_COMM_TIMEOUT", "90")), cross_check=True)
-            exchange["path"] = "library RCCL communicator (pdlp_iterate)" if on else "torch.distributed loop (library path declined)"
-            exchange["log"] = eng.lib_comm_log
-    drv = PdhgDriver(eng, restart_period=40, primal_update=True, adaptive=adaptive, precondition=args.ruiz, tol=1e-4)
-    sigma = estimate_sigma(eng, power_iters=20, seed=0)
-    drv.start(sigma)
-    setup_s = time.time() - t_setup
-
-    def run(iters):
-        done = 0
-        while done < iters:
-            done += drv.advance(iters - done)
 
     def fence():
         if comm is not None:
@@ -425,28 +476,48 @@ def main(argv=None):
         comm.all_reduce_max(tt)
         return float(tt)
 
-    period = drv.period
-    run(args.warmup)
-    extra = (-drv.tt) % period                 # untimed: up to (and including) the next restart check
-    run(extra)
-    assert drv.tt % period == 0
-    fence()
-    checks0, restarts0 = drv.checks, drv.n
-    t0 = time.time()
-    run(args.steps)
-    fence()
-    elapsed = max_over_ranks(time.time() - t0)
-    checks_in, restarts_in = drv.checks - checks0, drv.n - restarts0
-    # the cost of one restart check INCLUDING the restart work at the rate restarts fire (wall clock, synchronised), measured
-    # over the next whole periods: a check that evaluates the previous iterate too costs 2 products more than one that does
-    # not, and a restart adds its vector passes -- several periods average that out
-    run((-drv.tt) % period)
-    drv.check_seconds, c1, r1 = 0.0, drv.checks, drv.n
-    run(args.check_periods * period)
-    checks_m, restarts_m = drv.checks - c1, drv.n - r1
-    check_s = max_over_ranks(drv.check_seconds / max(1, checks_m))
-    drv.check_seconds = None
-    norm_elapsed = elapsed + (args.steps / period - checks_in) * check_s
+    def timed_region():
+        """warm-up, EXACTLY --steps timed iterations, then the cost of a restart check: one measurement of the headline number on
+        whatever drives the exchange right now (a fresh driver from x = y = 0 every time)"""
+        drv = PdhgDriver(eng, restart_period=40, primal_update=True, adaptive=adaptive, precondition=args.ruiz, tol=1e-4)
+        sigma = estimate_sigma(eng, power_iters=20, seed=0)
+        drv.start(sigma)
+
+        def run(iters):
+            done = 0
+            while done < iters:
+                done += drv.advance(iters - done)
+        period = drv.period
+        run(args.warmup)
+        extra = (-drv.tt) % period                 # untimed: up to (and including) the next restart check
+        run(extra)
+        assert drv.tt % period == 0
+        fence()
+        checks0, restarts0 = drv.checks, drv.n
+        t0 = time.time()
+        run(args.steps)
+        fence()
+        elapsed = max_over_ranks(time.time() - t0)
+        checks_in, restarts_in = drv.checks - checks0, drv.n - restarts0
+        # the cost of one restart check INCLUDING the restart work at the rate restarts fire (wall clock, synchronised), measured
+        # over the next whole periods: a check that evaluates the previous iterate too costs 2 products more than one that does
+        # not, and a restart adds its vector passes -- several periods average that out
+        run((-drv.tt) % period)
+        drv.check_seconds, c1, r1 = 0.0, drv.checks, drv.n
+        run(args.check_periods * period)
+        checks_m, restarts_m = drv.checks - c1, drv.n - r1
+        check_s = max_over_ranks(drv.check_seconds / max(1, checks_m))
+        drv.check_seconds = None
+        norm_elapsed = elapsed + (args.steps / period - checks_in) * check_s
+        return dict(period=period, extra=extra, elapsed=elapsed, checks_in=checks_in, restarts_in=restarts_in, checks_m=checks_m,
+                    restarts_m=restarts_m, check_s=check_s, norm_elapsed=norm_elapsed)
+
+    # N > 1: the headline is measured on the torch.distributed loop FIRST; the library's own communicator (first contact with a
+    # second RCCL communicator) is tried only afterwards, under a watchdog that prints the line already measured if it hangs
+    setup_s = time.time() - t_setup
+    reg = timed_region()
+    period, extra, elapsed, norm_elapsed = reg["period"], reg["extra"], reg["elapsed"], reg["norm_elapsed"]
+    checks_in, restarts_in, checks_m, restarts_m, check_s = reg["checks_in"], reg["restarts_in"], reg["checks_m"], reg["restarts_m"], reg["check_s"]
 
     try:
         roofline = measure_roofline(args, eng, dt, adaptive, world)
@@ -474,9 +545,58 @@ def main(argv=None):
         "roofline": roofline,
         "setup_s": round(setup_s, 1),
     }
+    out["config"].update(notes)
     if exchange is not None:
         out["config"]["exchange"] = exchange
-    out["config"].update(notes)
+        try:
+            out["timing"]["phases"] = exchange_phases(eng, comm, roofline, norm_elapsed / args.steps * 1e3)
+        except Exception as e:
+            out["timing"]["phases"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        if args.lib_comm == "auto" and comm.backend == "nccl" and eng.xchunks > 1:
+            # (a chunked exchange stays on torch.distributed's own collectives here: the library's form of it -- grouped broadcasts
+            # on a second stream -- has only ever run against the test stand-in, and a first contact belongs outside a benchmark)
+            exchange["path"] = "torch.distributed loop (chunked exchange: library driver not tried)"
+        elif args.lib_comm == "auto" and comm.backend == "nccl":
+            # The library's own RCCL communicator (one C call per restart period), cross-checked bit for bit against the loop just
+            # measured.  Whatever happens in here -- a hang in ncclCommInitRank included -- the line measured above is what gets
+            # printed: the watchdog prints it from rank 0 and ends every rank's process (a process with a stuck RCCL thread is
+            # poisoned; nothing of it is reused or destroyed).
+            import threading
+            limit = float(os.environ.get("PDLP_COMM_TIMEOUT", "90"))
+            fallback = json.dumps(dict(out, config=dict(out["config"], exchange=dict(
+                exchange, path=f"torch.distributed loop (library path abandoned by the watchdog after {2 * limit + 120:.0f} s)"))))
+            finished = threading.Event()
+
+            def watchdog():
+                if not finished.wait(2 * limit + 120):
+                    if rank == 0:
+                        print(fallback, flush=True)
+                    sys.stderr.write(f"bench.py: rank {rank}: library communicator phase hung; leaving with the torch.distributed line\n")
+                    sys.stderr.flush()
+                    os._exit(0)
+            threading.Thread(target=watchdog, daemon=True).start()
+            try:
+                on = eng.enable_library_comm(timeout=limit, cross_check=True)
+                exchange["log"] = eng.lib_comm_log
+                if on:
+                    reg2 = timed_region()
+                    v1, v2 = args.steps / norm_elapsed, args.steps / reg2["norm_elapsed"]
+                    exchange["torch_loop_value"], exchange["library_value"] = round(v1, 3), round(v2, 3)
+                    if v2 >= v1:
+                        exchange["path"] = "library RCCL communicator (pdlp_iterate)"
+                        out["value"], out["ms_per_step"] = round(v2, 3), round(reg2["norm_elapsed"] / args.steps * 1e3, 4)
+                        out["timing"].update(elapsed_s=round(reg2["elapsed"], 6), raw_value=round(args.steps / reg2["elapsed"], 3),
+                                             checks_in_timed_region=reg2["checks_in"], restarts_in_timed_region=reg2["restarts_in"],
+                                             check_ms=round(reg2["check_s"] * 1e3, 3), normalised_elapsed_s=round(reg2["norm_elapsed"], 6))
+                    else:
+                        exchange["path"] = "torch.distributed loop (library path works and is bit-identical, but was slower here)"
+                        eng.lib_comm = False
+                else:
+                    exchange["path"] = "torch.distributed loop (library path declined)"
+            except Exception as e:
+                exchange["path"] = f"torch.distributed loop (library path failed: {type(e).__name__})"
+                eng.lib_comm = False
+            finished.set()
     if args.solve_tol > 0:
         # time to tolerance (untimed part of the run, the engine of the timed region re-started from zero): the reference's default
         # tolerance fits a bench run; tighter ones are separate runs (tools/time_to_tol.py), recorded in profiles/time_to_tol.json
@@ -494,7 +614,7 @@ def main(argv=None):
         except Exception as e:
             out["time_to_tol"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        del drv, eng
+        del eng
         torch.cuda.empty_cache()
         try:
             out["cpu_baseline"] = cpu_baseline(args, torch.float64 if args.dtype != "f32" else dt)

@@ -33,6 +33,7 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("PDLP_GOLDEN_OUT", HERE)      # where the .npz files go (tests regenerate into a scratch folder and compare)
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.dont_write_bytecode = True
 sys.path.insert(0, "/root/reference/PDLP")
@@ -61,7 +62,7 @@ def lp_cases():
     cases["mixed_400x300"] = gen_lp(300, 400, 5, seed=12, recipe="mixed", ineq_frac=0.8)
     cases["mixed_300x400_alleq"] = gen_lp(400, 300, 5, seed=13, recipe="mixed", ineq_frac=0.0)
     cases["mixed_200x260_allineq"] = gen_lp(260, 200, 4, seed=14, recipe="mixed", ineq_frac=1.0)
-    cases["box_200x150"] = gen_lp(150, 200, 5, seed=15, recipe="box", ineq_frac=0.8)
+    cases["box_200x150"] = gen_lp(150, 200, 5, seed=15, recipe="box_v1", ineq_frac=0.8)      # (the recipe the stored fixtures were drawn with)
     return cases
 
 
@@ -111,7 +112,7 @@ def g1_step_fixed(cases):
                                                        lp.m_ineq, eta, omega, 1.0)
             if it in (1, 2, 40):
                 put(out, name, {f"x{it}": xx.flatten().numpy().copy(), f"y{it}": yy.flatten().numpy().copy()})
-    np.savez_compressed(os.path.join(HERE, "step_fixed.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "step_fixed.npz"), **out)
 
 
 def g2_step_adaptive(cases):
@@ -153,7 +154,7 @@ def g2_step_adaptive(cases):
     put(out, "denzero", dict(K=K.numpy(), c=c.numpy(), q=q.numpy(), l=l.numpy(), u=u.numpy(), m_ineq=2, eta_in=e.numpy(),
                              omega=om.numpy(), k=4, x1=xn.flatten().numpy(), y1=yn.flatten().numpy(),
                              eta_used=e_used.numpy(), eta_hat=e_hat.numpy(), j_out=j))
-    np.savez_compressed(os.path.join(HERE, "step_adaptive.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "step_adaptive.npz"), **out)
 
 
 def g3_kkt(cases):
@@ -171,7 +172,7 @@ def g3_kkt(cases):
             kkt = ref_helpers.KKT_error(col(px), col(py), col(lp.c), col(lp.q), K, lp.m_ineq, omega, inn, ipn, ld, ud, "cpu")
             put(out, f"{name}/{tag}", dict(x=px.numpy(), y=py.numpy(), omega=omega.numpy(), pr=pr.numpy(), dr=dr.numpy(),
                                           gap=gap.numpy(), p=po.numpy(), d_adj=da.numpy(), kkt=kkt.numpy()))
-    np.savez_compressed(os.path.join(HERE, "kkt.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "kkt.npz"), **out)
 
 
 _RESTART_RE = re.compile(r"^(Sufficient|Necessary|Artificial) restart at iteration (\d+) using the (Average|Current) iterate")
@@ -250,7 +251,7 @@ def g4_solve_trace(cases):
                                                                     k=k, n=n, j=j, status=status))
         print(f"G4 tiny adaptive={adaptive}: k={k} n={n} j={j} {status} obj={obj}")
     put(out, "tiny", dict(K=K.numpy(), c=c.numpy(), q=q.numpy(), l=l.numpy(), u=u.numpy(), m_ineq=1))
-    np.savez_compressed(os.path.join(HERE, "solve_trace.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "solve_trace.npz"), **out)
 
 
 def g5_primal_weight():
@@ -267,7 +268,7 @@ def g5_primal_weight():
         put(out, f"case{i}_zero", dict(x_prev=x.flatten().numpy(), x=x.flatten().numpy(), y_prev=yp.flatten().numpy(),
                                        y=y.flatten().numpy(), omega=om.numpy(), theta=0.5,
                                        omega_new=ref_enh.primal_weight_update(x, x, yp, y, om, 0.5).numpy()))
-    np.savez_compressed(os.path.join(HERE, "primal_weight.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "primal_weight.npz"), **out)
 
 
 def g6_ruiz(cases):
@@ -290,7 +291,7 @@ def g6_ruiz(cases):
                                                         K_s=Ks.numpy(), c_s=cs.flatten().numpy(), q_s=qs.flatten().numpy(),
                                                         l_s=ls.flatten().numpy(), u_s=us.flatten().numpy(),
                                                         D_col=D_col.flatten().numpy(), D_row=D_row.flatten().numpy()))
-    np.savez_compressed(os.path.join(HERE, "ruiz.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "ruiz.npz"), **out)
 
 
 def g7_power_iter(cases):
@@ -306,7 +307,7 @@ def g7_power_iter(cases):
             put(out, f"{name}/it{iters}", dict(b0=b0.flatten().numpy(), sigma=s.numpy(),
                                               sigma_exact=float(torch.linalg.matrix_norm(K.double(), 2))))
         put(out, name, lp_arrays(lp))
-    np.savez_compressed(os.path.join(HERE, "power_iter.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "power_iter.npz"), **out)
 
 
 def g8_mps():
@@ -324,7 +325,7 @@ def g8_mps():
         put(out, fn, dict(c=c.flatten().numpy(), K=K.numpy(), q=q.flatten().numpy(), m_ineq=m_ineq,
                           l=l.flatten().numpy(), u=u.flatten().numpy()))
         print(f"G8 {fn}: K {tuple(K.shape)} m_ineq={m_ineq}")
-    np.savez_compressed(os.path.join(HERE, "mps.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "mps.npz"), **out)
 
 
 def g9_afiro():
@@ -347,7 +348,7 @@ def g9_afiro():
         tag = f"afiro/{'adaptive' if adaptive else 'fixed'}_{'pw' if pw else 'nopw'}_{'ruiz' if precond else 'noruiz'}"
         put(out, tag, dict(b0=b0.flatten().numpy(), x=x.flatten().numpy(), obj=obj, k=k, n=n, j=j, status=status))
         print(f"G9 {tag}: k={k} n={n} j={j} {status} obj={obj:.6f} (HiGHS -464.753143)")
-    np.savez_compressed(os.path.join(HERE, "afiro.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "afiro.npz"), **out)
 
 
 def tiny_infeas_lps():
@@ -419,7 +420,7 @@ def g10_infeasibility(cases):
                 put(out, tag, dict(b0=b0.flatten().numpy(), infeas_tol=itol, x=x.flatten().numpy(), obj=obj, k=k, n=n, j=j,
                                    status=status))
                 print(f"G10 {tag}: k={k} n={n} j={j} {status} obj={obj:.6f}")
-    np.savez_compressed(os.path.join(HERE, "infeasibility.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "infeasibility.npz"), **out)
 
 
 class _TorchProxy:
@@ -494,7 +495,7 @@ def g11_fishnet(cases):
         sep = min(float((torch.sort(g)[0][1:] - torch.sort(g)[0][:-1]).min() / (g.abs().max() + 1e-30)) for g in gaps if g.numel() > 1)
         print(f"G11 {name}: 2^{i} points, k={k}: rounds={nrounds} weights={len(rands)} radius={float(radius):.5f} "
               f"eta={0.9 / sigmas[1]:.6f} smallest relative gap separation {sep:.2e}")
-    np.savez_compressed(os.path.join(HERE, "fishnet.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "fishnet.npz"), **out)
 
 
 def g12_forced_trace(cases, spec=(("mixed_400x300", (0, 3, 9, 20)), ("box_200x150", (0, 2, 7, 12))), fname="forced_trace.npz"):
@@ -540,7 +541,7 @@ def g12_forced_trace(cases, spec=(("mixed_400x300", (0, 3, 9, 20)), ("box_200x15
                                              x_out=st(5), y_out=st(6), eta_used=sc(7), eta_hat=sc(8)))
         rej = sum(1 for b in blocks for c_ in calls[40 * b:40 * b + 40] if c_[7] != c_[2])
         print(f"G12 {name}: {len(calls)} adaptive calls, blocks {blocks} recorded step by step ({rej} rejected steps), {status} k={k}")
-    np.savez_compressed(os.path.join(HERE, fname), **out)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
 
 
 def g13_forced_trace_more(cases):
@@ -566,5 +567,5 @@ if __name__ == "__main__":
     if "g11" in which: g11_fishnet(cases)
     if "g12" in which: g12_forced_trace(cases)
     if "g13" in which: g13_forced_trace_more(cases)
-    print("golden fixtures written to", HERE)
+    print("golden fixtures written to", OUT)
 

@@ -37,15 +37,70 @@ def test_spawn_ranks_relays_rank0_line(tmp_path, capfd):
 
 def test_spawn_ranks_fails_when_a_rank_fails(tmp_path, capfd):
     script = _script(tmp_path, """
-        import json, os, sys
+        import json, os, sys, time
         if int(os.environ["RANK"]) == 1:
             sys.exit(3)
+        time.sleep(60)                                       # (rank 0 would be stuck in a collective: the launcher must stop it)
         print(json.dumps({"metric": "x"}))
     """)
     rc = bench.spawn_ranks(2, [], script=script)
     out, err = capfd.readouterr()
     assert rc != 0 and out.strip() == ""                     # no result line from a failed job
     assert "failed" in err
+
+
+def test_spawn_ranks_relays_a_measured_line_when_ranks_hang_afterwards(tmp_path, capfd):
+    """a rank stuck in a communicator's teardown after the result line must not cost the number"""
+    script = _script(tmp_path, """
+        import json, os, sys, time
+        if int(os.environ["RANK"]) == 0:
+            print(json.dumps({"metric": "PDHG iterations/sec", "value": 1.5}), flush=True)
+        time.sleep(600)
+    """)
+    rc = bench.spawn_ranks(2, [], script=script, grace=1.0)
+    out, err = capfd.readouterr()
+    assert rc == 0 and json.loads(out.strip())["value"] == 1.5
+    assert "stopping the ranks" in err
+
+
+def test_spawn_ranks_gives_up_on_ranks_that_hang_before_a_line(tmp_path, capfd):
+    script = _script(tmp_path, "import time\ntime.sleep(600)\n")
+    rc = bench.spawn_ranks(2, [], script=script, launch_timeout=1.5)
+    out, err = capfd.readouterr()
+    assert rc != 0 and out.strip() == "" and "no result line" in err
+
+
+def test_spawn_ranks_keeps_the_line_when_a_rank_fails_after_it(tmp_path, capfd):
+    script = _script(tmp_path, """
+        import json, os, sys, time
+        if int(os.environ["RANK"]) == 0:
+            print(json.dumps({"metric": "PDHG iterations/sec", "value": 2.5}), flush=True)
+            time.sleep(600)
+        time.sleep(1.0)
+        sys.exit(7)
+    """)
+    rc = bench.spawn_ranks(2, [], script=script)
+    out, err = capfd.readouterr()
+    assert rc == 0 and json.loads(out.strip())["value"] == 2.5 and "measured before the failure" in err
+
+
+def test_spawn_ranks_hosts_the_rendezvous_store(tmp_path, capfd):
+    """no probe-and-release of a port; the ranks join a store the launcher keeps open"""
+    script = _script(tmp_path, """
+        import json, os
+        import torch.distributed as dist
+        assert os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True"
+        dist.init_process_group("gloo")
+        import torch
+        t = torch.tensor([float(dist.get_rank() + 1)])
+        dist.all_reduce(t)
+        if dist.get_rank() == 0:
+            print(json.dumps({"metric": "PDHG iterations/sec", "value": float(t)}), flush=True)
+        dist.destroy_process_group()
+    """)
+    rc = bench.spawn_ranks(2, [], script=script)
+    out, _ = capfd.readouterr()
+    assert rc == 0 and json.loads(out.strip())["value"] == 3.0
 
 
 def test_spawn_ranks_fails_without_a_result_line(tmp_path, capfd):

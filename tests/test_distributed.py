@@ -754,3 +754,28 @@ def test_sharded_delta_mode_infeasibility_detector_sees_the_whole_y():
         ret = man.dict()
         mp.spawn(_infeas_delta_worker, args=(2, port, ret), nprocs=2, join=True)
         assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def _agree_worker(rank, world, port, ret):
+    from torchpdlp_amd.distributed import agree_failed
+    _init(rank, world, port)
+    try:
+        got = [agree_failed(dist, rank, world, False, "none", 20.0),                   # nobody failed
+               agree_failed(dist, rank, world, True, "all", 20.0),                     # every rank alike (a bad option, a bad instance)
+               agree_failed(dist, rank, world, rank == 1, "one", 20.0)]                # rank 1 alone: everybody learns it
+        # a rank that fails while its peer sits in a collective: the peer never posts, the failing rank gets -1 after the timeout and
+        # must not have issued a collective of its own (rank 0 stands in for the blocked peer by simply not calling)
+        if rank == 1:
+            got.append(agree_failed(dist, rank, world, True, "stuck_peer", 1.0))
+        ret[rank] = got
+    finally:
+        dist.destroy_process_group()
+
+
+def test_failure_agreement_is_out_of_band_and_times_out():
+    """the CLI's per-instance failure count must not be a collective on the solve's process group"""
+    port = _free_port()
+    with mp.Manager() as man:
+        ret = man.dict()
+        mp.spawn(_agree_worker, args=(2, port, ret), nprocs=2, join=True)
+        assert ret[0] == [0, 2, 1] and ret[1] == [0, 2, 1, -1]

@@ -25,13 +25,34 @@ def close(a, b, rtol):
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
 
 
-def golden_lp(g, name, dtype=torch.float32):
+KERNEL_FAMILIES = ["csr", "tiled", "sorted"]        # k_csr_fused, k_tiled_fused (panels of 64 columns), k_csr_fused on column-sorted row blocks
+
+
+def use_kernel_family(eng, family):
+    """Put BOTH products of an engine on one kernel family, so that the reference's own vectors meet every kernel the library ships."""
+    if family == "csr":
+        return
+    if family == "sorted":
+        for tr in (0, 1):
+            eng.attach_sorted(tr)
+            assert "sorted" in eng.kernels[tr]
+        return
+    from torchpdlp_amd.tiled import build_tiles
+    for tr, (rp, ci, va), rows, cols in ((0, eng.K, eng.ml, eng.n), (1, eng.KT, eng.nl, eng.m)):
+        t = build_tiles(rp, ci, va, rows, cols, lw=6)
+        assert t is not None, "the golden LPs all fit the tile format"
+        eng.attach_tiles(tr, t)
+        assert eng.kernels[tr].startswith("tiled")
+
+
+def golden_lp(g, name, dtype=torch.float32, family="csr"):
     a = g.group(name)
     t = lambda v, dt=dtype: torch.tensor(np.asarray(v), dtype=dt, device=DEV)
     K = tp.CsrPair(int(a["m"]), int(a["n"]), t(a["rowptr"], torch.int32), t(a["colidx"], torch.int32), t(a["val"]))
     o = orc.OracleLP(a["m"], a["n"], a["m_ineq"], a["rowptr"], a["colidx"], a["val"], a["c"], a["q"], a["l"], a["u"],
                      dtype=np.float32 if dtype == torch.float32 else np.float64)
     eng = tp.PdlpEngine.from_full(K, t(a["c"]), t(a["q"]), t(a["l"]), t(a["u"]), int(a["m_ineq"]))
+    use_kernel_family(eng, family)
     return a, K, o, eng
 
 
@@ -105,10 +126,11 @@ def test_spmv_matches_oracle(shape):
 # ---------------------------------------------------------------------------------------------------
 # one PDHG step
 # ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("family", KERNEL_FAMILIES)
 @pytest.mark.parametrize("name", LP_CASES)
-def test_step_fixed_vs_golden_and_oracle(golden, name):
+def test_step_fixed_vs_golden_and_oracle(golden, name, family):
     g = golden("step_fixed.npz")
-    a, K, o, eng = golden_lp(g, name)
+    a, K, o, eng = golden_lp(g, name, family=family)
     eng.set_iterate(dev(a["x0"]), dev(a["y0"]))
     eng.set_step(float(a["eta"]), float(a["omega"]), float(a["theta"]), 0)
     xo, yo = a["x0"], a["y0"]
@@ -191,9 +213,10 @@ def test_reference_named_ops(golden):
 
 @pytest.mark.parametrize("name", LP_CASES)
 @pytest.mark.parametrize("tag", ["accept", "reject", "late"])
-def test_step_adaptive_vs_golden(golden, name, tag):
+@pytest.mark.parametrize("family", KERNEL_FAMILIES)
+def test_step_adaptive_vs_golden(golden, name, tag, family):
     g = golden("step_adaptive.npz")
-    a, K, o, eng = golden_lp(g, name)
+    a, K, o, eng = golden_lp(g, name, family=family)
     r = g.group(f"{name}/{tag}")
     eng.set_iterate(dev(a["x0"]), dev(a["y0"]))
     eng.set_step(float(r["eta_in"]), float(a["omega"]), float(a["theta"]), int(r["k"]) - 1)
@@ -266,10 +289,11 @@ def test_step_adaptive_zero_denominator(golden):
 # ---------------------------------------------------------------------------------------------------
 # KKT residuals, primal weight, power iteration
 # ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("family", KERNEL_FAMILIES)
 @pytest.mark.parametrize("name", LP_CASES)
-def test_kkt_vs_golden(golden, name):
+def test_kkt_vs_golden(golden, name, family):
     g = golden("kkt.npz")
-    a, K, o, eng = golden_lp(g, name)
+    a, K, o, eng = golden_lp(g, name, family=family)
     tags = sorted({c.split("/")[1] for c in g.cases(2) if c.startswith(name + "/")} & {"rand", "zero", "feas", "opt"})
     for tag in tags:
         r = g.group(f"{name}/{tag}")
@@ -320,14 +344,15 @@ FORCED = {"mixed_400x300": "forced_trace.npz", "box_200x150": "forced_trace.npz"
           "mixed_300x400_alleq": "forced_trace_more.npz", "mixed_200x260_allineq": "forced_trace_more.npz"}
 
 
+@pytest.mark.parametrize("family", KERNEL_FAMILIES)
 @pytest.mark.parametrize("name", sorted(FORCED))
-def test_forced_trace_adaptive_steps(golden, name):
+def test_forced_trace_adaptive_steps(golden, name, family):
     """Every step of recorded 40-iteration blocks of the reference's pdlp_algorithm(adaptive=True, primal_update=True)
     (tests/golden/forced_trace.npz), each taken from the reference's own state before it: accepted and rejected steps
     (quirk Q1), step sizes beyond eta_bar, iterates produced by restarts to the average.  Whole blocks cannot be compared:
     with eta above eta_bar the iteration expands rounding differences 3x per step (gen_golden.g12_forced_trace)."""
     g = golden(FORCED[name])
-    a, K, o, eng = golden_lp(g, name)
+    a, K, o, eng = golden_lp(g, name, family=family)
     blocks = [int(b) for b in a["blocks"]]
     assert len(blocks) >= 3
     rejected = 0
@@ -905,14 +930,35 @@ def test_infeasibility_detection_off_is_untouched_and_on_counts_passes(golden):
 # ---------------------------------------------------------------------------------------------------
 # BASELINE.json's full size (configs[3]/[4], the bench workload): too big for the oracle, so size-independent properties
 # ---------------------------------------------------------------------------------------------------
-def test_full_size_10Mx10M_properties(monkeypatch):
+@pytest.fixture(scope="module")
+def big_lp():
+    """the 10M x 10M bench LP and both CSR copies (16 GB), built once for the three full-size tests"""
+    lp = gen_lp(10_000_000, 10_000_000, 100, seed=0, device=DEV)
+    K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
+    assert K.nnz == 1_000_000_000
+    yield lp, K
+    del lp, K
+    torch.cuda.empty_cache()
+
+
+def _sampled_products_f64(rowptr, colidx, val, vec, nsample, seed):
+    """float64 numpy values of (M vec)[rows] for `nsample` random rows of a CSR matrix on the device: an oracle the kernels have no part in"""
+    nrows = rowptr.numel() - 1
+    rows = torch.randint(0, nrows, (nsample,), generator=torch.Generator().manual_seed(seed)).to(rowptr.device)
+    a, lens = rowptr[rows].long(), (rowptr[rows + 1] - rowptr[rows]).long()
+    seg = torch.repeat_interleave(torch.arange(nsample, device=rowptr.device), lens)
+    pos = a[seg] + (torch.arange(int(lens.sum()), device=rowptr.device) - torch.repeat_interleave(lens.cumsum(0) - lens, lens))
+    cols, vals = colidx[pos].cpu().numpy(), val[pos].cpu().numpy().astype(np.float64)
+    vh = vec.cpu().numpy().astype(np.float64)
+    return rows, np.bincount(seg.cpu().numpy(), weights=vals * vh[cols], minlength=nsample)
+
+
+def test_full_size_10Mx10M_properties(monkeypatch, big_lp):
     """10M x 10M, 1e9 non-zeros, the tiled kernels the benchmark times: linearity of both products, the adjoint identity
     <K x, y> = <x, K'y> between the two independently built tiled copies, agreement of the tiled and the CSR kernel on the
     whole matrix, one adaptive PDHG iteration + KKT pass on both kernel families, and the row sums of K against the CSR data"""
     n = 10_000_000
-    lp = gen_lp(n, n, 100, seed=0, device=DEV)
-    K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
-    assert K.nnz == 1_000_000_000
+    lp, K = big_lp
     monkeypatch.setenv("PDLP_TILED", "1")
     e1 = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
     assert all(t is not None and t.groups == 1 for t in e1.tiles)           # the fused tiled kernel on both matrices
@@ -923,6 +969,11 @@ def test_full_size_10Mx10M_properties(monkeypatch):
     lin = e1.spmv(2.0 * x1 - x2, False) - (2.0 * kx1 - kx2)
     assert float(lin.abs().max()) <= 2e-5 * float(kx1.abs().max())
     kty1 = e1.spmv(y1, True)
+    # values, not only properties: 4096 sampled rows of K x and of K'y against float64 numpy dot products over the CSR arrays
+    rows, want = _sampled_products_f64(K.rowptr, K.colidx, K.val, x1, 4096, seed=11)
+    close(kx1[rows], want, 2e-5)
+    cols, want_t = _sampled_products_f64(K.t_rowptr, K.t_colidx, K.t_val, y1, 4096, seed=12)
+    close(kty1[cols], want_t, 2e-5)
     lhs, rhs = float((kx1.double() * y1.double()).sum()), float((x1.double() * kty1.double()).sum())
     assert abs(lhs - rhs) <= 1e-6 * (float(kx1.double().norm()) * float(y1.double().norm()))
     ones = torch.ones(n, device=DEV)
@@ -1151,14 +1202,13 @@ def _sample_pairs(K, rows):
     return out
 
 
-def test_config4_ruiz_adaptive_10Mx10M_properties(monkeypatch):
+def test_config4_ruiz_adaptive_10Mx10M_properties(monkeypatch, big_lp):
     """configs[4] at its full size: sparse Ruiz (ruiz_precondition, enhancements.py:4-71) + adaptive steps + primal weight on the
     10M x 10M instance.  Too big for the oracle, so: both CSR copies and the rebuilt tiles carry the same scaled values, they are
     D_row K D_col, the scaled vectors follow :64-67, the un-scaled KKT pass equals the KKT pass of the un-scaled problem at the
     un-scaled point (pdhg.py:157-161), and the preconditioned adaptive solve reaches the reference's tolerance on the ORIGINAL LP"""
     n = 10_000_000
-    lp = gen_lp(n, n, 100, seed=0, device=DEV)
-    K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
+    lp, K = big_lp
     Ks, c_s, q_s, l_s, u_s, dp, secs = tp.ruiz_precondition(lp.c, K, lp.q, lp.l, lp.u, device=DEV)
     D_col, D_row = dp[0].reshape(-1), dp[1].reshape(-1)
     assert Ks.nnz == K.nnz == 1_000_000_000 and torch.equal(Ks.colidx, K.colidx) and torch.equal(Ks.t_colidx, K.t_colidx)
@@ -1240,20 +1290,18 @@ class _OneOfEight:
         pass
 
 
-def test_config3_one_eighth_shard_of_10Mx10M(monkeypatch):
+def test_config3_one_eighth_shard_of_10Mx10M(monkeypatch, big_lp):
     """configs[3]: the 10M x 10M instance row/column-block sharded over 8 GPUs -- one rank's shard (rank 3: rows 3.75M..5M of K and
     of K') on one GPU: the split tiled product (local panels first, the others after the all-gather: pdlp_*_half_begin), the
     unsplit tiled product and the CSR kernel must agree on both half-steps and on the KKT sums"""
     n, W, rank = 10_000_000, 8, 3
-    lp = gen_lp(n, n, 100, seed=0, device=DEV)
-    K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
+    lp, K = big_lp
     from torchpdlp_amd.distributed import shard_arrays
     args = shard_arrays(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq, rank, W)
     args.pop("part")
     r0, r1 = args["rows"]
     c0, c1 = args["cols"]
     assert (r0, r1, c0, c1) == (3_750_000, 5_000_000, 3_750_000, 5_000_000)
-    del K
     g = torch.Generator(device=DEV).manual_seed(4)
     xf = torch.minimum(torch.maximum(torch.randn(n, device=DEV, generator=g), lp.l), lp.u)
     yf = torch.randn(n, device=DEV, generator=g)

@@ -4,6 +4,8 @@ This is what pins the oracle: every operator of the hot path (SURVEY.md section 
 outputs of /root/reference/PDLP produced by tests/golden/gen_golden.py.  float32 throughout, as
 the reference; tolerances are for summation-order differences only.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -368,3 +370,25 @@ def test_torch_coo_restatement_vs_reference(golden, name):
         out = lp.kkt(col(r["x"]), col(r["y"]), torch.tensor(np.float32(r["omega"])))
         for key in ("pr", "dr", "gap", "p", "d_adj", "kkt"):
             np.testing.assert_allclose(float(out[key]), float(r[key][0]), rtol=2e-5, atol=2e-5 * (1 + abs(float(r["p"][0]))))
+
+
+# ---------------------------------------------------------------------------------------------------
+# provenance of the fixtures: the committed generator reproduces them (build container only: it imports the live reference)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.skipif(not os.path.isdir("/root/reference/PDLP"), reason="the reference is mounted in the build container only")
+def test_generator_reproduces_the_stored_fixtures(tmp_path):
+    """tests/golden/gen_golden.py g1 g2 g3 (run against the live reference) writes the very arrays that are committed: every key of
+    step_fixed / step_adaptive / kkt.npz, bit for bit -- so nobody who reruns the script silently replaces reference-pinned data"""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, PDLP_GOLDEN_OUT=str(tmp_path), PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, os.path.join(here, "golden", "gen_golden.py"), "g1", "g2", "g3"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for name in ("step_fixed.npz", "step_adaptive.npz", "kkt.npz"):
+        new, old = np.load(tmp_path / name), np.load(os.path.join(here, "golden", name))
+        assert sorted(new.files) == sorted(old.files), name
+        for key in old.files:
+            assert new[key].dtype == old[key].dtype and new[key].shape == old[key].shape, (name, key)
+            assert new[key].tobytes() == old[key].tobytes(), (name, key)

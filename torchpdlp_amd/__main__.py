@@ -72,14 +72,14 @@ def main(argv=None) -> int:
     files = sorted(f for f in os.listdir(args.instance_path) if f.endswith(".mps"))       # main.py:83
     results = []
 
-    def failed_ranks(failed: bool) -> int:
-        """how many ranks failed on this instance (collective: every rank calls it once per instance, success or not)"""
+    agree_timeout = float(os.environ.get("PDLP_FAIL_AGREE_TIMEOUT", "60"))
+
+    def failed_ranks(failed: bool, tag: str) -> int:
+        """how many ranks failed on this instance (-1: no agreement in time); out of band, never a collective: distributed.agree_failed"""
         if world == 1:
             return int(failed)
-        host = dist.get_backend() == "gloo"
-        t = torch.tensor([int(failed)], dtype=torch.int32, device="cpu" if host else torch.device("cuda", torch.cuda.current_device()))
-        dist.all_reduce(t)
-        return int(t)
+        from .distributed import agree_failed
+        return agree_failed(dist, rank, world, failed, tag, agree_timeout)
 
     def write_results():
         os.makedirs(args.output_path, exist_ok=True)
@@ -115,20 +115,21 @@ def main(argv=None) -> int:
             print(f"Solver uses {r.time:.4f} seconds.\nStatus: {r.status}")
             results.append({"File": name, "Objective": f"{r.objective:.6f}", "Iterations (k)": r.iterations, "Restarts (n)": r.restarts,
                             "KKT Passes (j)": r.kkt_passes, "Time (s)": f"{r.time:.4f}", "Status": r.status})      # main.py:142-150
-            bad = failed_ranks(False)
+            bad = failed_ranks(False, name)
         except Exception as e:          # the reference records the failure and goes on (main.py:152-162)
             print(f"Solver failed for {name}. Error: {e}")
             results.append(_fail_row(name, "Solver failed", e))
-            bad = failed_ranks(True)
-        if 0 < bad < world:
-            # only some ranks failed (out of memory on one shard, ...): the ranks are out of step and the next instance would hang
-            # in its first collective.  Rank 0 saves what there is -- the rows of the instances solved so far -- and the job ends
-            # non-zero.  (A failure every rank hits alike -- an unsupported option combination, a bad instance -- is a row like
-            # any other: the loop goes on, as the reference's does.)
-            print(f"rank {rank}: {bad} of {world} ranks failed on {name}; leaving the sharded run", file=sys.stderr, flush=True)
+            bad = failed_ranks(True, name)
+        if bad != 0 and bad != world:
+            # only some ranks failed (out of memory on one shard, ...), or the ranks could not agree in time: they are out of step and
+            # the next instance would hang in its first collective.  Rank 0 saves what there is -- the rows of the instances solved so
+            # far -- and the job ends non-zero.  (A failure every rank hits alike -- an unsupported option combination, a bad
+            # instance -- is a row like any other: the loop goes on, as the reference's does.)
+            print(f"rank {rank}: " + (f"{bad} of {world} ranks failed" if bad > 0 else f"no agreement within {agree_timeout:.0f} s") +
+                  f" on {name}; leaving the sharded run", file=sys.stderr, flush=True)
             if rank == 0:
                 if results[-1]["Status"] == "Solved" or not results[-1]["Status"].startswith("Solver failed"):
-                    results[-1] = _fail_row(name, "Solver failed", RuntimeError(f"{bad} of {world} ranks failed"))
+                    results[-1] = _fail_row(name, "Solver failed", RuntimeError(f"{bad} of {world} ranks failed" if bad > 0 else "ranks out of step"))
                 write_results()
             sys.stdout.flush()
             os._exit(3)

@@ -68,10 +68,6 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x)
 // the VALU write of it: the other scan's instruction and one s_nop provide them.
 __device__ __forceinline__ void wave_incl_scan2_u32(uint32_t& a, uint32_t& b)
 {
-#ifdef PDLP_NO_SCAN2
-    a = wave_incl_scan_u32(a);
-    b = wave_incl_scan_u32(b);
-#else
 #define PDLP_SCAN_STEP(ctl) "v_add_u32_dpp %0, %0, %0 " ctl "\n\tv_add_u32_dpp %1, %1, %1 " ctl "\n\ts_nop 0\n\t"
     asm("s_nop 1\n\t"
         PDLP_SCAN_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
@@ -82,7 +78,6 @@ __device__ __forceinline__ void wave_incl_scan2_u32(uint32_t& a, uint32_t& b)
         PDLP_SCAN_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
         : "+v"(a), "+v"(b));
 #undef PDLP_SCAN_STEP
-#endif
 }
 
 template <typename T> __device__ __forceinline__ T block_sum(T v, T* buf)
@@ -1539,6 +1534,15 @@ int iterate_direct(pdlp_handle h, int iters, int adaptive)
     return PDLP_OK;
 }
 
+// Graph replay was asked for (PDLP_GRAPH) and cannot be had: say so once per process -- the iteration falls back to plain launches,
+// which is correct but slower on small LPs, and would otherwise show up only as a slower benchmark.
+void graph_abandoned(const char* why)
+{
+    static bool said = false;
+    if (!said) std::fprintf(stderr, "libpdlp_hip: PDLP_GRAPH: graph capture abandoned (%s); iterating with direct launches\n", why);
+    said = true;
+}
+
 // the executable graph of two iterations from the current buffer roles (captured on first use), or nullptr
 pdlp_solver::IterGraph* pair_graph(pdlp_handle h, int adaptive)
 {
@@ -1556,6 +1560,7 @@ pdlp_solver::IterGraph* pair_graph(pdlp_handle h, int adaptive)
     hipStream_t user = h->stream;
     if (hipStreamBeginCapture(h->gstream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
+        graph_abandoned("hipStreamBeginCapture failed");
         h->graph_ok = false;
         h->sums_broken = true;        // (the running sums were not kept while replay was on: no running average before the next restart)
         return nullptr;
@@ -1572,6 +1577,7 @@ pdlp_solver::IterGraph* pair_graph(pdlp_handle h, int adaptive)
         hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0) != hipSuccess) {
         if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
+        graph_abandoned(rc != PDLP_OK ? "a launch failed during capture" : "hipStreamEndCapture / hipGraphInstantiate failed");
         h->graph_ok = false;
         h->sums_broken = true;        // (the running sums were not kept while replay was on: no running average before the next restart)
         return nullptr;

@@ -335,3 +335,20 @@ def gen_lp_shard(n: int, m: int, nnz_per_row: int, seed: int, comm: Comm, device
         eng.part, eng.nnz_local = part, nnz_local
         return eng
     return engine_from_shard(args, comm, precision, precondition)
+
+
+def agree_failed(dist, rank: int, world: int, failed: bool, tag: str, timeout_s: float = 60.0) -> int:
+    """How many ranks failed at the point ``tag``; -1 if the ranks cannot agree within ``timeout_s``.  Out of band, over the process
+    group's key-value store -- NOT a collective: a rank that raises in the middle of a solve has peers blocked inside the solve's own
+    all-gathers / all-reduces, and a collective issued from its exception path would pair with one of those (undefined behaviour
+    under RCCL: a hang or garbage).  Ranks that fail alike (an unsupported option, a bad instance: before any collective) post
+    their flags at once; a rank that fails alone waits ``timeout_s`` for flags that never come and gets -1."""
+    import datetime
+    store = dist.distributed_c10d._get_default_store()
+    store.set(f"pdlp/fail/{tag}/{rank}", "1" if failed else "0")
+    keys = [f"pdlp/fail/{tag}/{r}" for r in range(world)]
+    try:
+        store.wait(keys, datetime.timedelta(seconds=timeout_s))
+    except Exception:
+        return -1
+    return sum(int(store.get(k) == b"1") for k in keys)

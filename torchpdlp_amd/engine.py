@@ -438,11 +438,20 @@ class PdlpEngine:
         product with K (max over the ranks).  Measured with stand-ins on one GPU (profiles/r03_split_chunks.log): one piece wins
         while the all-gather takes less than about half a product (the extra launches and partial-sum slots of a chunked exchange
         cost more than the overlap gains), two pieces win beyond that (-7 % at 8 ranks with a 0.2 ms all-gather, -12 % at 4 ranks
-        with 0.3 ms).  Collective: every rank calls it; all end up with the same choice."""
+        with 0.3 ms).  Collective: every rank calls it (whatever kernel its own shard uses); all end up with the same choice.
+        Call it before the iterate is set or between restart periods: ``pdlp_set_exchange_chunks`` refuses while a product is pending."""
         out = dict(chunks=1, all_gather_ms=None, product_ms=None)
-        if self.comm is None or self.tiles[0] is None or self.split_info(0)["local_groups"] == 0:
+        if self.comm is None:
             return out
-        full = self.buffer(N.BUF_GDX if self.delta else N.BUF_XBAR)
+        # Every decision below is GLOBAL: a rank whose shard is not tiled or not split (CSR fallback, too many row blocks) must not
+        # leave before the collectives the others are about to issue, and all ranks must end up with the same number of pieces.
+        mine = int(self.tiles[0] is not None and self.split_info(0)["local_groups"] > 0)
+        flag = torch.tensor([-float(mine)], dtype=torch.float64, device=self.device)
+        self.comm.all_reduce_max(flag)                      # max of the negated flags = -(min of the flags)
+        if float(flag[0]) != -1.0:
+            return out
+        live = self.buffer(N.BUF_GDX if self.delta else N.BUF_XBAR)
+        full = torch.zeros_like(live)                       # a scratch vector of the exchange's size: the live buffer is not touched
         vin = torch.zeros(self.n, dtype=self.dtype, device=self.device)
         res = torch.empty(self.ml, dtype=self.dtype, device=self.device)
         ev = lambda: torch.cuda.Event(enable_timing=True)
@@ -465,10 +474,13 @@ class PdlpEngine:
         ag, prod = float(t[0]), float(t[1])
         chunks = 2 if ag > 0.5 * prod else 1
         self.set_exchange_chunks(chunks)
-        if chunks > 1 and any(len(self.exchange_plan(tr)) != chunks for tr in (0, 1) if self.tiles[tr] is not None):
-            chunks = 1                        # (too few panels for pieces on some matrix: stay with one all-gather)
+        # too few panels for pieces on some matrix of some rank: everybody stays with one all-gather (the plan is a function of the
+        # block length alone, so this test gives the same answer everywhere; the reduction makes that a guarantee, not a hope)
+        ok = torch.tensor([-float(all(len(self.exchange_plan(tr)) == chunks for tr in (0, 1)))], dtype=torch.float64, device=self.device)
+        self.comm.all_reduce_max(ok)
+        if chunks > 1 and float(ok[0]) != -1.0:
+            chunks = 1
             self.set_exchange_chunks(1)
-        full.zero_()
         out.update(chunks=chunks, all_gather_ms=round(ag, 4), product_ms=round(prod, 4))
         return out
 

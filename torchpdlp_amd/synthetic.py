@@ -4,7 +4,7 @@ The LP form is the reference's (``/root/reference/PDLP/util.py:76-84``)::
 
     min c'x   s.t.  K[:m_ineq] x >= q[:m_ineq],  K[m_ineq:] x = q[m_ineq:],  l <= x <= u
 
-Two recipes:
+Three recipes (``box_v1``: the single-generator form of ``box`` the golden fixtures were drawn with; frozen):
 
 ``box``    (every array is seeded per 2^16-row chunk: ``box_rows`` / ``box_vectors`` let one rank of a sharded run generate
            exactly its rows of the same instance -- ``distributed.gen_lp_shard``)
@@ -150,10 +150,27 @@ def gen_lp(n: int, m: int, nnz_per_row: int, seed: int = 0, device="cpu",
         return SyntheticLP(m, n, m_ineq, rowptr, col, val, vec["c"].to(dtype), q.to(dtype), vec["l"].to(dtype), vec["u"].to(dtype),
                            vec["x_feas"].to(dtype))
 
-    if recipe != "mixed":
+    if recipe not in ("mixed", "box_v1"):
         raise ValueError(f"unknown recipe {recipe!r}")
     col = _regular_pattern(m, n, k, gen, device, chunk_rows)
     rowptr = torch.arange(0, (m + 1) * k, k, dtype=torch.int64, device=device).to(torch.int32)
+
+    if recipe == "box_v1":
+        # The "box" distribution drawn from ONE generator in sequence: the recipe as it stood when tests/golden/*.npz were
+        # generated (the box_200x150 case).  Frozen so that tests/golden/gen_golden.py keeps reproducing its fixtures byte for
+        # byte; new code uses "box" (chunk-seeded, shardable).
+        val = torch.empty(m * k, dtype=dtype, device=device)
+        for r0 in range(0, m * k, chunk_rows * 8):
+            r1 = min(m * k, r0 + chunk_rows * 8)
+            val[r0:r1] = torch.rand(r1 - r0, generator=gen, device=device, dtype=torch.float32).to(dtype)
+        x_feas = U(n, -10.0, 10.0)
+        kx = _regular_matvec(col, val, x_feas, m, k, chunk_rows)
+        q = kx.clone()
+        q[:m_ineq] -= U(m_ineq, 0.1, 5.0)
+        l = torch.clamp(x_feas - U(n, 1.0, 5.0), min=-1e4)
+        u = torch.clamp(x_feas + U(n, 1.0, 5.0), max=1e4)
+        c = torch.randn(n, generator=gen, device=device, dtype=torch.float64)
+        return SyntheticLP(m, n, m_ineq, rowptr, col, val, c.to(dtype), q.to(dtype), l.to(dtype), u.to(dtype), x_feas.to(dtype))
 
     val = torch.randn(m * k, generator=gen, device=device, dtype=torch.float64).to(dtype)
     # bound classes: 0 boxed, 1 lower only, 2 upper only, 3 free
