@@ -533,7 +533,13 @@ def _libcomm_worker(rank, world, port, ret, tiled):
             whole = {}
             trace = (lambda *a: print(f"[rank {rank}]", *a, flush=True)) if os.environ.get("PDLP_TEST_TRACE") else (lambda *a: None)
             # (CSR kernels never split a product, but the exchange may still travel in pieces: same collectives on every rank)
-            for chunks in (((1, 2, 3) if (world == 2 and name == "f32") else (1, 2)) if tiled else ((1, 2) if name == "f32" else (1,))):
+            # (suite budget: ranks sharing one card take turns on it.  Every precision meets the one-piece exchange on both step rules;
+            #  the chunked exchange is covered by f32 on 2 and 3 ranks (3 pieces on 2 ranks) and by mixed precision on 2 ranks)
+            if tiled:
+                chunk_list = {"f32": (1, 2, 3) if world == 2 else (1, 2), "mixed": (1, 2) if world == 2 else (1,)}.get(name, (1,))
+            else:
+                chunk_list = (1, 2) if name == "f32" else (1,)
+            for chunks in chunk_list:
                 trace(name, "chunks", chunks)
                 # chunked exchange (tiled products only): the gathered vector travels in `chunks` pieces and the panels a piece
                 # completes are multiplied while the next piece is on the wire -- again the same bits on both drivers, and the
@@ -549,7 +555,7 @@ def _libcomm_worker(rank, world, port, ret, tiled):
                             assert all(plan[c][1] == plan[c + 1][0] and plan[c][0] % 64 == 0 for c in range(want - 1))
                             info = e.split_info(tr)
                             assert (info["local_groups"] >= 1 and info["other_groups"] >= want) if tiled else info["local_groups"] == 0, info
-                for adaptive in (True, False):
+                for adaptive in ((True, False) if chunks == 1 else (True,)):
                     outs = []
                     for e in (eA, eB):
                         trace(name, chunks, "adaptive" if adaptive else "fixed", "library driver" if e is eB else "torch loop")
@@ -572,7 +578,7 @@ def _libcomm_worker(rank, world, port, ret, tiled):
                         np.testing.assert_allclose(ka, whole[adaptive][2], rtol=10 * tol)
             for e in (eA, eB):
                 e.set_exchange_chunks(1)
-            if not tiled and name in ("f32", "mixed"):
+            if not tiled and name == ("f32" if world == 2 else "mixed"):
                 # a whole restarted solve: identical restart decisions, counters and solution on both paths
                 sols = []
                 for e in (eA, eB):
@@ -675,6 +681,9 @@ def _ruiz_worker(rank, world, port, ret):
         assert float(res.norm()) <= 1.01 * TOL * (1 + float(lp.q.norm()))
         assert float((xu - lp.l).clamp(max=0).abs().max()) <= 1e-9 and float((lp.u - xu).clamp(max=0).abs().max()) <= 1e-9
         assert abs(float((lp.c * xu).sum()) - obj) <= 1e-9 * (1 + abs(obj))
+        if world > 2:      # (suite budget: the single-rank comparison and the user-facing entry points run in the 2-rank case)
+            ret[rank] = "ok"
+            return
         if rank == 0:      # the same solve on one rank reaches the same optimum
             e1 = engine_from_shard(dict(shard_arrays(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq, 0, 1, balance="rows")), None,
                                    precision="mixed", precondition=True)
