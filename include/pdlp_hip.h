@@ -67,10 +67,10 @@ typedef struct pdlp_problem {
     int64_t m_ineq;             /* the first m_ineq constraints are ">=" rows (util.py:250-261)             */
     int64_t row0, row1;         /* this rank's rows of K   (0,m on a single GPU)                            */
     int64_t col0, col1;         /* this rank's rows of K'  (0,n on a single GPU)                            */
-    const int32_t* K_rowptr;    /* [row1-row0+1], K_rowptr[0] == 0                                          */
+    const int64_t* K_rowptr;    /* [row1-row0+1], K_rowptr[0] == 0; 64-bit: a handle may hold more than 2^31 non-zeros */
     const int32_t* K_colidx;    /* [nnz_K]  global column indices in [0,n)                                  */
     const void* K_val;          /* [nnz_K]                                                                  */
-    const int32_t* KT_rowptr;   /* [col1-col0+1]                                                            */
+    const int64_t* KT_rowptr;   /* [col1-col0+1]                                                            */
     const int32_t* KT_colidx;   /* [nnz_KT] global row indices in [0,m)                                     */
     const void* KT_val;         /* [nnz_KT]                                                                 */
     const void* c;              /* [col1-col0]                                                              */
@@ -101,7 +101,7 @@ typedef struct pdlp_tiles {
                                    epilogue is fused, > 1 (<= 8, <= npanel) = partial row sums + k_rowsum_epilogue */
     const uint32_t* idx;        /* [items]                                                                 */
     const void* val;            /* [items] in the problem's precision                                      */
-    const int32_t* tile_ptr;    /* [nblk*npanel + 1] item offsets, multiples of 256                        */
+    const int64_t* tile_ptr;    /* [nblk*npanel + 1] item offsets (64-bit), multiples of 256               */
     const uint32_t* cnt;        /* 4-bit counts, 16-byte aligned: [tiles][512][4] words 0..3, then [tiles][cw-4][512]; cw = 5|3                                                 */
     /* the remainder: items the tiles could not hold (more than 15 of a row in one tile, more than 255 of 64 consecutive rows,
      * more than cap in a tile), as segments of <= 512 items of the rows that have any; rem_rows_n = 0: none */
@@ -136,7 +136,7 @@ void pdlp_destroy(pdlp_handle h);
 int pdlp_attach_tiles(pdlp_handle h, int transpose, const pdlp_tiles* t);
 /* The CSR kernel's row blocks (built by pdlp_create: <= 256 rows, <= 2048 non-zeros each): *blocks = device array of
  * (first row, first non-zero) pairs, nblk + 1 of them.  For building the column-sorted copy below. */
-int pdlp_schedule_info(pdlp_handle h, int transpose, int32_t* nblk, const int32_t** blocks);
+int pdlp_schedule_info(pdlp_handle h, int transpose, int32_t* nblk, const int64_t** blocks);
 /* Optional column-sorted copy of the items of K (transpose = 0) or K' (1) for the CSR kernel: inside every row block the items
  * are sorted by column; sval = the values in that order (precision of the matrix), sidx = (slot << 21) | (column - cbase[block]),
  * slot = the item's position in CSR order inside its block.  A wave's gathers then cover consecutive sorted items -- a few cache
@@ -325,10 +325,10 @@ int pdlp_probe_stream_read(const void* buf, int64_t bytes, int reps, void* strea
 
 /* ---- Ruiz equilibration on CSR (ruiz_precondition enhancements.py:4-71) ---------------------- */
 /* norm[i] = sqrt(max_p |val[p]|) over row i, replaced by 1 when < eps (:49-50 / :54-55) */
-int pdlp_csr_row_scale_factors(int dtype, int64_t rows, const int32_t* rowptr, const void* val, double eps,
+int pdlp_csr_row_scale_factors(int dtype, int64_t rows, const int64_t* rowptr, const void* val, double eps,
                                void* norm, void* stream);
 /* val[p] /= norm[row(p)]                      (:52 / :57 on the copy whose rows are being scaled) */
-int pdlp_csr_div_rows(int dtype, int64_t rows, const int32_t* rowptr, void* val, const void* norm, void* stream);
+int pdlp_csr_div_rows(int dtype, int64_t rows, const int64_t* rowptr, void* val, const void* norm, void* stream);
 /* val[p] /= norm_full[colidx[p]]              (the same scaling applied to the transposed copy)   */
 int pdlp_csr_div_cols(int dtype, int64_t nnz, const int32_t* colidx, void* val, const void* norm_full, void* stream);
 /* elementwise helpers for D /= norm, c*D, l/D ... (:51,:56,:64-67); op: 0 a*=b, 1 a/=b */

@@ -67,7 +67,7 @@ def lp_cases():
 
 
 def lp_arrays(lp):
-    return dict(m=lp.m, n=lp.n, m_ineq=lp.m_ineq, rowptr=lp.rowptr.numpy(), colidx=lp.colidx.numpy(),
+    return dict(m=lp.m, n=lp.n, m_ineq=lp.m_ineq, rowptr=lp.rowptr.numpy().astype(np.int32), colidx=lp.colidx.numpy(),
                 val=lp.val.numpy(), c=lp.c.numpy(), q=lp.q.numpy(), l=lp.l.numpy(), u=lp.u.numpy())
 
 

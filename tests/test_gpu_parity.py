@@ -3,6 +3,8 @@
 float32 like the reference.  Tolerances cover summation order only (the GPU reduces rows with up
 to 64 lanes and norms in float64): single operators 2e-5 relative, 40 chained steps 1e-4.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1001,6 +1003,59 @@ def test_full_size_10Mx10M_properties(monkeypatch, big_lp):
     np.testing.assert_allclose(b[2], a[2], rtol=1e-4)
     for key in ("pr", "dr", "p", "d_adj", "kkt"):
         np.testing.assert_allclose(b[3][key], a[3][key], rtol=1e-4)
+
+
+def test_more_than_2_31_nonzeros_in_one_handle(monkeypatch):
+    """VERDICT r3 (missing 4, next 8): 12M x 12M with 200 non-zeros per row = 2.4e9 > 2^31 - 1 non-zeros per matrix copy in ONE handle.
+    Row pointers, tile pointers and schedule offsets are 64-bit from the host arrays to the kernels.  Values of K x and K'y on rows
+    whose items lie beyond the 32-bit range against float64 numpy dot products, on the tiled and on the CSR kernels; the adjoint
+    identity; one adaptive iteration + KKT pass on both kernel families."""
+    n, k = 12_000_000, 200
+    lp = gen_lp(n, n, k, seed=0, device=DEV)
+    K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
+    assert K.nnz == n * k > 2 ** 31 and K.rowptr.dtype == torch.int64 and int(K.rowptr[-1]) == n * k == int(K.t_rowptr[-1])
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x1, y1 = torch.randn(n, device=DEV, generator=g), torch.randn(n, device=DEV, generator=g)
+
+    def sampled(rowptr, colidx, val, vec, seed):          # rows from the last tenth: every item position is above 2^31
+        nrows = rowptr.numel() - 1
+        rows = (torch.randint(0, nrows // 10, (2048,), generator=torch.Generator().manual_seed(seed)) + (nrows - nrows // 10)).to(DEV)
+        assert int(rowptr[rows].min()) > 2 ** 31
+        a, lens = rowptr[rows], rowptr[rows + 1] - rowptr[rows]
+        seg = torch.repeat_interleave(torch.arange(rows.numel(), device=DEV), lens)
+        pos = a[seg] + (torch.arange(int(lens.sum()), device=DEV) - torch.repeat_interleave(lens.cumsum(0) - lens, lens))
+        cols, vals = colidx[pos].cpu().numpy(), val[pos].cpu().numpy().astype(np.float64)
+        return rows, np.bincount(seg.cpu().numpy(), weights=vals * vec.cpu().numpy().astype(np.float64)[cols], minlength=rows.numel())
+    rows, want = sampled(K.rowptr, K.colidx, K.val, x1, 21)
+    cols, want_t = sampled(K.t_rowptr, K.t_colidx, K.t_val, y1, 22)
+    x0 = torch.minimum(torch.maximum(x1, lp.l), lp.u)
+    y0 = y1.clone()
+    y0[:lp.m_ineq].clamp_(min=0)
+    outs = []
+    for tiled in ("1", "0"):
+        monkeypatch.setenv("PDLP_TILED", tiled)
+        e = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
+        if tiled == "1":
+            assert all(t is not None and t.groups == 1 and int(t.tile_ptr[-1]) > 2 ** 31 for t in e.tiles)
+        else:
+            assert e.tiles == [None, None]
+        kx, kty = e.spmv(x1, False), e.spmv(y1, True)
+        close(kx[rows], want, 3e-5)
+        close(kty[cols], want_t, 3e-5)
+        lhs, rhs = float((kx.double() * y1.double()).sum()), float((x1.double() * kty.double()).sum())
+        assert abs(lhs - rhs) <= 1e-6 * (float(kx.double().norm()) * float(y1.double().norm()))
+        e.set_iterate(x0, y0)
+        e.set_step(0.01, 1.0, 1.0, 0)
+        e.iterate(2, True)
+        x, y = e.get_iterate(N.CUR)
+        outs.append((x.clone(), y.clone(), e.scalars()["eta"], e.kkt(N.CUR, 1.0)["kkt"], kx, kty))
+        del e
+        torch.cuda.empty_cache()
+    a, b = outs
+    for i in (0, 1, 4, 5):
+        close(a[i], b[i].cpu().numpy(), 3e-5)
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-4)
+    np.testing.assert_allclose(a[3], b[3], rtol=1e-4)
 
 
 def test_kty_reuse_after_restart_checks_changes_nothing(monkeypatch, golden):

@@ -235,16 +235,36 @@ def test_bench_command_line_contract(monkeypatch):
     assert set(tr["n10000000_k100_f32_adaptive_g1_tiled"]) >= {"primal", "dual"}
 
 
-def test_one_handle_is_limited_to_int32_offsets_and_says_so():
-    """row pointers, tile offsets and schedule entries are int32, so one handle (= one rank) holds fewer than 2^31
-    non-zeros per matrix copy.  The bound is a hard, explicit error -- not a wrap-around -- and names the remedy."""
-    import pytest, torch
-    from torchpdlp_amd.sparse import _counts_to_rowptr
-    ok = _counts_to_rowptr(torch.tensor([2 ** 30, 2 ** 30 - 1], dtype=torch.int64))
-    assert ok.dtype == torch.int32 and int(ok[-1]) == 2 ** 31 - 1
-    with pytest.raises(ValueError, match=r"2\^31-1 non-zeros in one shard: split the problem across more ranks"):
-        _counts_to_rowptr(torch.tensor([2 ** 30, 2 ** 30], dtype=torch.int64))
-    # the tile builder declines (None -> the CSR kernel stays) before any 32-bit item offset could overflow
-    from torchpdlp_amd import tiled as T
-    import inspect
-    assert "2 ** 31" in inspect.getsource(T.build_tiles)
+def test_offsets_are_64_bit_end_to_end():
+    """VERDICT r3 (missing 4): one handle may hold more than 2^31 - 1 non-zeros per matrix copy.  Row pointers are int64 from the
+    host arrays to the C ABI (include/pdlp_hip.h: K_rowptr, KT_rowptr, tile_ptr, the schedule), column indices stay int32."""
+    import os, re, torch
+    from torchpdlp_amd.sparse import CsrPair, _counts_to_rowptr
+    rp = _counts_to_rowptr(torch.tensor([2 ** 31, 2 ** 31, 5], dtype=torch.int64))
+    assert rp.dtype == torch.int64 and rp.tolist() == [0, 2 ** 31, 2 ** 32, 2 ** 32 + 5]
+    K = CsrPair(2, 3, torch.tensor([0, 2, 3], dtype=torch.int32), torch.tensor([0, 2, 1]), torch.tensor([1.0, 2.0, 3.0]))
+    assert K.rowptr.dtype == K.t_rowptr.dtype == torch.int64 and K.colidx.dtype == K.t_colidx.dtype == torch.int32
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "pdlp_hip.h")).read()
+    for field in ("K_rowptr", "KT_rowptr", "tile_ptr"):
+        assert re.search(r"const int64_t\*\s+" + field + ";", hdr), field
+    assert "const int64_t** blocks" in hdr
+
+
+def test_chunked_transpose_equals_the_single_sort():
+    """torch.sort takes at most INT_MAX elements, so matrices beyond 2^30 entries are transposed in row chunks (sparse.csr_transpose):
+    the same arrays as the one stable sort, incl. a row longer than a chunk and empty rows"""
+    import torch
+    from torchpdlp_amd.sparse import csr_transpose
+    g = torch.Generator().manual_seed(0)
+    m, n = 300, 211
+    lens = torch.randint(0, 9, (m,), generator=g)
+    lens[17], lens[100] = 150, 0
+    rp = torch.zeros(m + 1, dtype=torch.int64)
+    rp[1:] = torch.cumsum(lens, 0)
+    ci = torch.randint(0, n, (int(rp[-1]),), generator=g).to(torch.int32)
+    va = torch.randn(int(rp[-1]), generator=g)
+    ref = csr_transpose(rp, ci, va, m, n)
+    for chunk in (37, 64, 1000):
+        got = csr_transpose(rp, ci, va, m, n, chunk_nnz=chunk)
+        assert all(torch.equal(a, b) for a, b in zip(ref, got)), chunk

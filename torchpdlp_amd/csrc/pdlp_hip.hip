@@ -152,11 +152,11 @@ int rccl_load(const char* path)
 // host side
 // ------------------------------------------------------------------------------------------------
 struct Schedule {
-    int32_t* blk = nullptr;   // device, nblk+1 pairs (first row, first non-zero)
+    int64_t* blk = nullptr;   // device, nblk+1 pairs (first row, first non-zero)
     int nblk = 0;
     int grid = 0;
     // rows longer than NNZ_CAP, cut into chunks of NNZ_CAP non-zeros
-    int32_t* lch = nullptr;   // device, [2*nchunks] (first, end) non-zero of every chunk
+    int64_t* lch = nullptr;   // device, [2*nchunks] (first, end) non-zero of every chunk
     int32_t* lrow = nullptr;  // device, [nlong] the rows
     int32_t* lptr = nullptr;  // device, [nlong+1] their chunk ranges
     void* longpart = nullptr; // device, [nchunks] chunk sums
@@ -195,7 +195,7 @@ inline int64_t max_chunks(int64_t nnz) { return 2 * (nnz / NNZ_CAP) + 2; }
 inline int64_t max_long(int64_t nnz) { return nnz / NNZ_CAP + 1; }
 constexpr int LONG_GRID = 64;
 
-void build_long_rows_host(const std::vector<int32_t>& rp, int64_t rows, std::vector<int32_t>& lch, std::vector<int32_t>& lrow,
+void build_long_rows_host(const std::vector<int64_t>& rp, int64_t rows, std::vector<int64_t>& lch, std::vector<int32_t>& lrow,
                           std::vector<int32_t>& lptr)
 {
     lch.clear(); lrow.clear(); lptr.clear();
@@ -204,8 +204,8 @@ void build_long_rows_host(const std::vector<int32_t>& rp, int64_t rows, std::vec
         const int64_t a = rp[r], e = rp[r + 1];
         if (e - a <= NNZ_CAP) continue;
         for (int64_t c = a; c < e; c += NNZ_CAP) {
-            lch.push_back((int32_t)c);
-            lch.push_back((int32_t)(c + NNZ_CAP < e ? c + NNZ_CAP : e));
+            lch.push_back(c);
+            lch.push_back(c + NNZ_CAP < e ? c + NNZ_CAP : e);
         }
         lrow.push_back((int32_t)r);
         lptr.push_back((int32_t)(lch.size() / 2));
@@ -213,7 +213,7 @@ void build_long_rows_host(const std::vector<int32_t>& rp, int64_t rows, std::vec
 }
 
 // out = (first row, first non-zero) of every block, then (rows, nnz) as the end marker: 2 * (blocks + 1) entries
-void build_schedule_host(const std::vector<int32_t>& rp, int64_t rows, std::vector<int32_t>& out)
+void build_schedule_host(const std::vector<int64_t>& rp, int64_t rows, std::vector<int64_t>& out)
 {
     out.clear();
     int64_t r = 0;
@@ -229,7 +229,7 @@ void build_schedule_host(const std::vector<int32_t>& rp, int64_t rows, std::vect
             ++e;
         }
         if (e == r) e = r + 1;   // a single row longer than NNZ_CAP: its own (skipped) block, done in chunks
-        out.push_back((int32_t)e);
+        out.push_back(e);
         out.push_back(rp[e]);
         r = e;
     }
@@ -386,7 +386,7 @@ int launch_mat(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* 
         HIP_TRY(hipGetLastError());
         return PDLP_OK;
     }
-    const int32_t* rp = transpose ? h->p.KT_rowptr : h->p.K_rowptr;
+    const int64_t* rp = transpose ? h->p.KT_rowptr : h->p.K_rowptr;
     const int32_t* ci = transpose ? h->p.KT_colidx : h->p.K_colidx;
     const TV* va = (const TV*)(transpose ? h->p.KT_val : h->p.K_val);
     if (s.sidx)
@@ -1087,12 +1087,12 @@ int64_t layout(const pdlp_problem* p, int64_t nnzK, int64_t nnzKT, int64_t* offs
     offs[k++] = c.take(pgrid * NACC * 8);                         // 15    partB
     offs[k++] = c.take(PDLP_NRED * 8);                            // 16    red
     offs[k++] = c.take(PDLP_NSCAL * 8);                           // 17    sc
-    offs[k++] = c.take((max_blocks(ml, nnzK) + 1) * 8);           // 18    schedule K
-    offs[k++] = c.take((max_blocks(nl, nnzKT) + 1) * 8);          // 19    schedule K'
+    offs[k++] = c.take((max_blocks(ml, nnzK) + 1) * 16);          // 18    schedule K  (pairs of 64-bit words)
+    offs[k++] = c.take((max_blocks(nl, nnzKT) + 1) * 16);         // 19    schedule K'
     offs[k++] = c.take(rowsum_groups(nl > ml ? nl : ml) * ((nl > ml ? nl : ml) + (int64_t)TNT * TRPT_MAX_ANY) * es);   // 20  rowsum scratch
     for (int t = 0; t < 2; ++t) {                                 // 21..28 long rows of K, then of K'
         const int64_t nnz = t == 0 ? nnzK : nnzKT;
-        offs[k++] = c.take(max_chunks(nnz) * 2 * 4);              //   chunk (first, end)
+        offs[k++] = c.take(max_chunks(nnz) * 2 * 8);              //   chunk (first, end), 64-bit
         offs[k++] = c.take(max_long(nnz) * 4);                    //   rows
         offs[k++] = c.take((max_long(nnz) + 1) * 4);              //   chunk ranges
         offs[k++] = c.take(max_chunks(nnz) * es);                 //   chunk sums
@@ -1115,13 +1115,13 @@ int64_t layout(const pdlp_problem* p, int64_t nnzK, int64_t nnzKT, int64_t* offs
     return c.off;
 }
 
-int read_last_rowptr(const int32_t* rp, int64_t rows, int64_t* nnz, hipStream_t stream)
+int read_last_rowptr(const int64_t* rp, int64_t rows, int64_t* nnz, hipStream_t stream)
 {
     // the arrays may just have been produced by kernels on the caller's stream (a non-blocking stream is not ordered
     // against the null stream's copy): read on that stream and wait
-    int32_t v = 0;
+    int64_t v = 0;
     if (rows > 0) {
-        HIP_TRY(hipMemcpyAsync(&v, rp + rows, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(&v, rp + rows, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
     }
     *nnz = v;
@@ -1135,7 +1135,7 @@ int read_last_rowptr(const int32_t* rp, int64_t rows, int64_t* nnz, hipStream_t 
 // ================================================================================================
 extern "C" {
 
-int pdlp_abi_version(void) { return 14; }  // 14: pdlp_probe_stream_read; 13: chunked exchange (pdlp_set_exchange_chunks, pdlp_exchange_plan, pdlp_half_chunk); 12: count words of a tile laid out for coalesced loads; 11: pdlp_comm_load; 10: pdlp_set_anchors; 9: pdlp_attach_sorted; 8: running products, pdlp_flush_average(h, adaptive); 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
+int pdlp_abi_version(void) { return 15; }  // 15: 64-bit row pointers, tile pointers and schedule offsets (more than 2^31 non-zeros per handle); 14: pdlp_probe_stream_read; 13: chunked exchange (pdlp_set_exchange_chunks, pdlp_exchange_plan, pdlp_half_chunk); 12: count words of a tile laid out for coalesced loads; 11: pdlp_comm_load; 10: pdlp_set_anchors; 9: pdlp_attach_sorted; 8: running products, pdlp_flush_average(h, adaptive); 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
 
 const char* pdlp_strerror(int code)
 {
@@ -1171,10 +1171,10 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     if (rc != PDLP_OK || !out) return PDLP_ERR_INVALID;
     HIP_TRY(hipSetDevice(p->device));
     const int64_t nl = p->col1 - p->col0, ml = p->row1 - p->row0;
-    std::vector<int32_t> rpK((size_t)ml + 1, 0), rpKT((size_t)nl + 1, 0);
+    std::vector<int64_t> rpK((size_t)ml + 1, 0), rpKT((size_t)nl + 1, 0);
     hipStream_t pstream = (hipStream_t)p->stream;
-    if (ml > 0) HIP_TRY(hipMemcpyAsync(rpK.data(), p->K_rowptr, (size_t)(ml + 1) * 4, hipMemcpyDeviceToHost, pstream));
-    if (nl > 0) HIP_TRY(hipMemcpyAsync(rpKT.data(), p->KT_rowptr, (size_t)(nl + 1) * 4, hipMemcpyDeviceToHost, pstream));
+    if (ml > 0) HIP_TRY(hipMemcpyAsync(rpK.data(), p->K_rowptr, (size_t)(ml + 1) * 8, hipMemcpyDeviceToHost, pstream));
+    if (nl > 0) HIP_TRY(hipMemcpyAsync(rpKT.data(), p->KT_rowptr, (size_t)(nl + 1) * 8, hipMemcpyDeviceToHost, pstream));
     HIP_TRY(hipStreamSynchronize(pstream));     // (ordered behind whatever produced the arrays on that stream)
     if (rpK[0] != 0 || rpKT[0] != 0) return PDLP_ERR_INVALID;
     int64_t offs[48];
@@ -1204,7 +1204,7 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     for (int i = 0; i < 3; ++i) h->kxb[i] = w + offs[11 + i];
     h->partA = (double*)(w + offs[14]); h->partB = (double*)(w + offs[15]);
     h->red = (double*)(w + offs[16]); h->sc = (double*)(w + offs[17]);
-    h->sK.blk = (int32_t*)(w + offs[18]); h->sKT.blk = (int32_t*)(w + offs[19]);
+    h->sK.blk = (int64_t*)(w + offs[18]); h->sKT.blk = (int64_t*)(w + offs[19]);
     h->rowsum = (void*)(w + offs[20]);
     h->dxf = w + offs[29]; h->dyf = w + offs[30]; h->lam_prev = w + offs[31]; h->ktdy = w + offs[32];
     h->ktyb[0] = w + offs[33]; h->ktyb[1] = w + offs[34];
@@ -1239,31 +1239,32 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     h->graph_ok = side && std::getenv("PDLP_GRAPH") != nullptr;
     h->use_split = false;
 
-    std::vector<int32_t> sched;
+    std::vector<int64_t> sched;
     build_schedule_host(rpK, ml, sched);
     h->sK.nblk = ml > 0 ? (int)sched.size() / 2 - 1 : 0;
     h->sK.grid = h->sK.nblk < MAX_GRID ? h->sK.nblk : MAX_GRID;
     auto upload = [&](void* dst, const void* src, size_t bytes) {      // ordered with later work on the caller's stream
         return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess;
     };
-    rc = upload(h->sK.blk, sched.data(), sched.size() * 4) ? PDLP_OK : PDLP_ERR_HIP_BASE - 1;
+    rc = upload(h->sK.blk, sched.data(), sched.size() * 8) ? PDLP_OK : PDLP_ERR_HIP_BASE - 1;
     build_schedule_host(rpKT, nl, sched);
     h->sKT.nblk = nl > 0 ? (int)sched.size() / 2 - 1 : 0;
     h->sKT.grid = h->sKT.nblk < MAX_GRID ? h->sKT.nblk : MAX_GRID;
-    if (rc == PDLP_OK && !upload(h->sKT.blk, sched.data(), sched.size() * 4)) rc = PDLP_ERR_HIP_BASE - 1;
+    if (rc == PDLP_OK && !upload(h->sKT.blk, sched.data(), sched.size() * 8)) rc = PDLP_ERR_HIP_BASE - 1;
     // rows longer than NNZ_CAP
     for (int t = 0; t < 2 && rc == PDLP_OK; ++t) {
         Schedule& sc = t == 0 ? h->sK : h->sKT;
-        std::vector<int32_t> lch, lrow, lptr;
+        std::vector<int64_t> lch;
+        std::vector<int32_t> lrow, lptr;
         build_long_rows_host(t == 0 ? rpK : rpKT, t == 0 ? ml : nl, lch, lrow, lptr);
-        sc.lch = (int32_t*)(w + offs[21 + 4 * t]); sc.lrow = (int32_t*)(w + offs[22 + 4 * t]);
+        sc.lch = (int64_t*)(w + offs[21 + 4 * t]); sc.lrow = (int32_t*)(w + offs[22 + 4 * t]);
         sc.lptr = (int32_t*)(w + offs[23 + 4 * t]); sc.longpart = (void*)(w + offs[24 + 4 * t]);
         sc.nchunks = (int)(lch.size() / 2); sc.nlong = (int)lrow.size();
         sc.lgrid = sc.nlong > 0 ? (int)((sc.nlong + BLOCK - 1) / BLOCK < LONG_GRID ? (sc.nlong + BLOCK - 1) / BLOCK : LONG_GRID) : 0;
         const int64_t work = (int64_t)sc.nblk + sc.nchunks;
         sc.grid = (int)(work < MAX_GRID ? work : MAX_GRID);
         if (sc.nlong > 0) {
-            if (!upload(sc.lch, lch.data(), lch.size() * 4) || !upload(sc.lrow, lrow.data(), lrow.size() * 4) ||
+            if (!upload(sc.lch, lch.data(), lch.size() * 8) || !upload(sc.lrow, lrow.data(), lrow.size() * 4) ||
                 !upload(sc.lptr, lptr.data(), lptr.size() * 4))
                 rc = PDLP_ERR_HIP_BASE - 1;
         }
@@ -1337,7 +1338,7 @@ int pdlp_attach_tiles(pdlp_handle h, int transpose, const pdlp_tiles* t)
     return configure_split(h, transpose != 0);
 }
 
-int pdlp_schedule_info(pdlp_handle h, int transpose, int32_t* nblk, const int32_t** blocks)
+int pdlp_schedule_info(pdlp_handle h, int transpose, int32_t* nblk, const int64_t** blocks)
 {
     if (!h || !nblk || !blocks) return PDLP_ERR_INVALID;
     const Schedule& s = transpose ? h->sKT : h->sK;
@@ -2000,7 +2001,7 @@ int pdlp_probe_stream_read(const void* buf, int64_t bytes, int reps, void* strea
 }
 
 // ---- Ruiz building blocks -------------------------------------------------------------------------
-int pdlp_csr_row_scale_factors(int dtype, int64_t rows, const int32_t* rowptr, const void* val, double eps, void* norm, void* stream)
+int pdlp_csr_row_scale_factors(int dtype, int64_t rows, const int64_t* rowptr, const void* val, double eps, void* norm, void* stream)
 {
     if (rows < 0 || (dtype != PDLP_F32 && dtype != PDLP_F64)) return PDLP_ERR_INVALID;
     if (rows == 0) return PDLP_OK;
@@ -2015,7 +2016,7 @@ int pdlp_csr_row_scale_factors(int dtype, int64_t rows, const int32_t* rowptr, c
     return PDLP_OK;
 }
 
-int pdlp_csr_div_rows(int dtype, int64_t rows, const int32_t* rowptr, void* val, const void* norm, void* stream)
+int pdlp_csr_div_rows(int dtype, int64_t rows, const int64_t* rowptr, void* val, const void* norm, void* stream)
 {
     if (rows < 0 || (dtype != PDLP_F32 && dtype != PDLP_F64)) return PDLP_ERR_INVALID;
     if (rows == 0) return PDLP_OK;

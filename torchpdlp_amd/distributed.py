@@ -134,7 +134,7 @@ def _block_rows(rowptr, colidx, val, lo: int, hi: int, B: int, index_map: torch.
     if B > hi - lo:
         rp = torch.cat([rp, rp[-1:].expand(B - (hi - lo))])
     ci = index_map[colidx[a:b].long()].to(torch.int32)
-    return rp.to(torch.int32).contiguous(), ci.contiguous(), val[a:b].contiguous()
+    return rp.contiguous(), ci.contiguous(), val[a:b].contiguous()
 
 
 def _block_vec(v: Optional[torch.Tensor], lo: int, hi: int, B: int, fill: float = 0.0):
@@ -316,7 +316,7 @@ def gen_lp_shard_arrays(n: int, m: int, nnz_per_row: int, seed: int, comm: Comm,
         rp = torch.cat([rp, rp[-1:].expand(part.Bm - (r_hi - r_lo))])
     vd = dtype if vec_dtype is None else vec_dtype
     bv = lambda v, lo, hi, B: _block_vec(v.to(vd), lo, hi, B)
-    return dict(m=part.mp, n=part.np_, m_ineq=r * part.Bm + ni, K_rows=(rp.to(torch.int32), col, val), KT_rows=(t_rp, t_ci, t_va),
+    return dict(m=part.mp, n=part.np_, m_ineq=r * part.Bm + ni, K_rows=(rp, col, val), KT_rows=(t_rp, t_ci, t_va),
                 c=bv(vec["c"], c_lo, c_hi, part.Bn), q=bv(q, 0, r_hi - r_lo, part.Bm), l=bv(vec["l"], c_lo, c_hi, part.Bn),
                 u=bv(vec["u"], c_lo, c_hi, part.Bn), rows=part.rows(r), cols=part.cols(r), part=part, nnz_local=int(col.numel()))
 

@@ -120,10 +120,11 @@ class PdlpEngine:
         if exact is not None and not self.mixed:
             raise ValueError("`exact` (the float64 matrix behind a float32 rounding) belongs to mixed precision")
         i32 = lambda t: t.to(device=self.device, dtype=torch.int32).contiguous()
+        i64 = lambda t: t.to(device=self.device, dtype=torch.int64).contiguous()        # row pointers: 64-bit in the ABI
         fv = lambda t, ln: None if t is None else as_vec(t, ln, self.device, self.dtype)
         # keep every tensor the library points into alive
-        self.K = (i32(K_rows[0]), i32(K_rows[1]), K_rows[2].to(self.mat_dtype).contiguous())
-        self.KT = (i32(KT_rows[0]), i32(KT_rows[1]), KT_rows[2].to(self.device, self.mat_dtype).contiguous())
+        self.K = (i64(K_rows[0]), i32(K_rows[1]), K_rows[2].to(self.mat_dtype).contiguous())
+        self.KT = (i64(KT_rows[0]), i32(KT_rows[1]), KT_rows[2].to(self.device, self.mat_dtype).contiguous())
         self.c, self.l, self.u = fv(c, self.nl), fv(l, self.nl), fv(u, self.nl)
         self.q = fv(q, self.ml)
         self.d_col, self.d_row = fv(d_col, self.nl), fv(d_row, self.ml)
@@ -240,7 +241,7 @@ class PdlpEngine:
         nb, bp = C.c_int32(0), C.c_void_p()
         N.check(self.lib.pdlp_schedule_info(self.h, transpose, C.byref(nb), C.byref(bp)), "pdlp_schedule_info")
         off = bp.value - self.workspace.data_ptr()
-        blk = self.workspace[off:off + (nb.value + 1) * 8].view(torch.int32).view(-1, 2)
+        blk = self.workspace[off:off + (nb.value + 1) * 16].view(torch.int64).view(-1, 2)
         first = blk[:, 1].long()                                   # first non-zero of every block (and the end)
         lens = first[1:] - first[:-1]
         dev = self.device

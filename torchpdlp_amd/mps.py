@@ -175,7 +175,7 @@ def mps_to_standard_form(mps_file, device="cpu", support_sparse=True, verbose=Fa
     c, (rowptr, colidx, vals, m, n), q, m_ineq, l, u = parse_mps(mps_file, compat=compat)
     dev = torch.device(device)
     t = lambda a: torch.tensor(a, dtype=dtype, device=dev).view(-1, 1)          # util.py:240-246: float32 column vectors
-    K = CsrPair(m, n, torch.from_numpy(rowptr).to(torch.int32), torch.from_numpy(colidx).to(torch.int32),
+    K = CsrPair(m, n, torch.from_numpy(rowptr).to(torch.int64), torch.from_numpy(colidx).to(torch.int32),
                 torch.from_numpy(vals).to(dtype)).to(dev)
     if verbose:
         print(f"Using Sparse operations ({m} x {n}, {K.nnz} non-zeros)")

@@ -78,8 +78,9 @@ def ruiz_precondition_shard(shard: dict, comm, max_iter=20, eps=1e-6) -> dict:
     (r0, r1), (c0, c1) = shard["rows"], shard["cols"]
     ml, nl = r1 - r0, c1 - c0
     i32 = lambda t: t.to(device=dev, dtype=torch.int32).contiguous()
-    K_blk = (i32(rp), i32(ci), va.clone())
-    KT_blk = (i32(t_rp), i32(t_ci), t_va.to(dev).clone())
+    i64 = lambda t: t.to(device=dev, dtype=torch.int64).contiguous()
+    K_blk = (i64(rp), i32(ci), va.clone())
+    KT_blk = (i64(t_rp), i32(t_ci), t_va.to(dev).clone())
     vec = lambda v, ln: as_vec(v, ln, dev, dt).clone()
     c_s, q_s, l_s, u_s = vec(shard["c"], nl), vec(shard["q"], ml), vec(shard["l"], nl), vec(shard["u"], nl)
     D_row = torch.ones(ml, dtype=dt, device=dev)

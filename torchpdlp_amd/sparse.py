@@ -1,4 +1,5 @@
-"""The constraint matrix as the HIP kernels want it: CSR of K and CSR of K' (int32 indices).
+"""The constraint matrix as the HIP kernels want it: CSR of K and CSR of K' (int32 column indices, int64 row pointers: one
+matrix copy may hold more than 2^31 non-zeros).
 
 The reference keeps ``K`` as a dense or COO torch tensor (``/root/reference/PDLP/util.py:240-267``)
 and multiplies with ``K @ v`` / ``K.T @ v``.  Here both products are row-parallel SpMVs over
@@ -15,24 +16,66 @@ import torch
 def _counts_to_rowptr(counts: torch.Tensor) -> torch.Tensor:
     rp = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=counts.device)
     torch.cumsum(counts, 0, out=rp[1:])
-    if int(rp[-1]) >= 2 ** 31:
-        raise ValueError("more than 2^31-1 non-zeros in one shard: split the problem across more ranks")
-    return rp.to(torch.int32)
+    return rp
 
 
-def csr_transpose(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, m: int, n: int
+_SORT_LIMIT = 1 << 30       # torch.sort takes at most INT_MAX elements: larger matrices are transposed in row chunks
+
+
+def csr_transpose(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, m: int, n: int, chunk_nnz: int = _SORT_LIMIT
                   ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """CSR of the transpose; rows of the result keep the original row order (stable sort)."""
-    counts = (rowptr[1:] - rowptr[:-1]).long()
-    rows = torch.repeat_interleave(torch.arange(m, dtype=torch.int32, device=val.device), counts)
-    _, order = torch.sort(colidx, stable=True)
-    t_col = rows[order]
-    del rows
-    t_val = val[order]
-    del order
-    t_rowptr = _counts_to_rowptr(torch.bincount(colidx, minlength=n) if colidx.numel() else
-                                 torch.zeros(n, dtype=torch.int64, device=val.device))
-    return t_rowptr, t_col.contiguous(), t_val.contiguous()
+    """CSR of the transpose; rows of the result keep the original row order (stable sort).  Matrices with more than
+    ``chunk_nnz`` entries go through in chunks of whole rows: every chunk is sorted by column on its own and scattered to where the
+    one big stable sort would have put it (start of the column + what earlier chunks hold of that column + rank inside the chunk)."""
+    nnz = int(colidx.numel())
+    dev = val.device
+    rp = rowptr.long()
+    if nnz <= chunk_nnz:
+        counts = rp[1:] - rp[:-1]
+        rows = torch.repeat_interleave(torch.arange(m, dtype=torch.int32, device=dev), counts)
+        _, order = torch.sort(colidx, stable=True)
+        t_col = rows[order]
+        del rows
+        t_val = val[order]
+        del order
+        t_rowptr = _counts_to_rowptr(torch.bincount(colidx, minlength=n) if nnz else torch.zeros(n, dtype=torch.int64, device=dev))
+        return t_rowptr, t_col.contiguous(), t_val.contiguous()
+    # chunk boundaries: whole rows, at most chunk_nnz entries each (a single longer row stands alone and is cut by entries)
+    cuts = [0]
+    rp_h = rp.cpu()
+    while cuts[-1] < m:
+        r0 = cuts[-1]
+        r1 = int(torch.searchsorted(rp_h, rp_h[r0] + chunk_nnz, right=True)) - 1
+        cuts.append(min(m, max(r1, r0 + 1)))
+    col_counts = torch.zeros(n, dtype=torch.int64, device=dev)
+    per_chunk = []
+    for r0, r1 in zip(cuts[:-1], cuts[1:]):
+        a, b = int(rp_h[r0]), int(rp_h[r1])
+        c = torch.zeros(n, dtype=torch.int64, device=dev)
+        for p0 in range(a, b, chunk_nnz):              # (pieces only when one row alone exceeds the limit)
+            c += torch.bincount(colidx[p0:min(b, p0 + chunk_nnz)], minlength=n)
+        per_chunk.append(c)
+        col_counts += c
+    t_rowptr = _counts_to_rowptr(col_counts)
+    t_col = torch.empty(nnz, dtype=torch.int32, device=dev)
+    t_val = torch.empty(nnz, dtype=val.dtype, device=dev)
+    base = t_rowptr[:-1].clone()                       # where the next chunk's entries of every column go
+    for (r0, r1), c in zip(zip(cuts[:-1], cuts[1:]), per_chunk):
+        a, b = int(rp_h[r0]), int(rp_h[r1])
+        for p0 in range(a, b, chunk_nnz):
+            p1 = min(b, p0 + chunk_nnz)
+            cc = colidx[p0:p1]
+            rows = (torch.searchsorted(rp, torch.arange(p0, p1, device=dev), right=True) - 1).to(torch.int32)
+            cs, order = torch.sort(cc, stable=True)
+            cpiece = torch.bincount(cc, minlength=n) if (p1 - p0) != (b - a) else c
+            excl = torch.cumsum(cpiece, 0) - cpiece     # first position of every column's run in the sorted piece
+            csl = cs.long()
+            dest = base[csl] + (torch.arange(p1 - p0, device=dev) - excl[csl])
+            t_col[dest] = rows[order]
+            t_val[dest] = val[p0:p1][order]
+            base += cpiece
+            del rows, cs, order, csl, dest, excl
+    return t_rowptr, t_col, t_val
 
 
 class CsrPair:
@@ -40,12 +83,12 @@ class CsrPair:
 
     def __init__(self, m: int, n: int, rowptr, colidx, val, t_rowptr=None, t_colidx=None, t_val=None):
         self.m, self.n = int(m), int(n)
-        self.rowptr = rowptr.to(torch.int32).contiguous()
+        self.rowptr = rowptr.to(torch.int64).contiguous()
         self.colidx = colidx.to(torch.int32).contiguous()
         self.val = val.contiguous()
         if t_rowptr is None:
             t_rowptr, t_colidx, t_val = csr_transpose(self.rowptr, self.colidx, self.val, self.m, self.n)
-        self.t_rowptr = t_rowptr.to(torch.int32).contiguous()
+        self.t_rowptr = t_rowptr.to(torch.int64).contiguous()
         self.t_colidx = t_colidx.to(torch.int32).contiguous()
         self.t_val = t_val.contiguous()
         if self.rowptr.numel() != self.m + 1 or self.t_rowptr.numel() != self.n + 1:

@@ -34,7 +34,7 @@ class SyntheticLP:
     m: int
     n: int
     m_ineq: int
-    rowptr: torch.Tensor   # int32 [m+1]
+    rowptr: torch.Tensor   # int64 [m+1]
     colidx: torch.Tensor   # int32 [nnz], sorted inside each row (duplicates possible, rare)
     val: torch.Tensor      # dtype [nnz]
     c: torch.Tensor        # [n]
@@ -143,7 +143,7 @@ def gen_lp(n: int, m: int, nnz_per_row: int, seed: int = 0, device="cpu",
     if recipe == "box":
         vec = box_vectors(n, m, seed, device, ineq_frac)
         col, val = box_rows(n, k, seed, 0, m, device, dtype)
-        rowptr = torch.arange(0, (m + 1) * k, k, dtype=torch.int64, device=device).to(torch.int32)
+        rowptr = torch.arange(0, (m + 1) * k, k, dtype=torch.int64, device=device)
         kx = _regular_matvec(col, val, vec["x_feas"], m, k, chunk_rows)
         q = kx.clone()
         q[:m_ineq] -= vec["slack"]
@@ -153,7 +153,7 @@ def gen_lp(n: int, m: int, nnz_per_row: int, seed: int = 0, device="cpu",
     if recipe not in ("mixed", "box_v1"):
         raise ValueError(f"unknown recipe {recipe!r}")
     col = _regular_pattern(m, n, k, gen, device, chunk_rows)
-    rowptr = torch.arange(0, (m + 1) * k, k, dtype=torch.int64, device=device).to(torch.int32)
+    rowptr = torch.arange(0, (m + 1) * k, k, dtype=torch.int64, device=device)
 
     if recipe == "box_v1":
         # The "box" distribution drawn from ONE generator in sequence: the recipe as it stood when tests/golden/*.npz were

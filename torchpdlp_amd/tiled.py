@@ -68,7 +68,7 @@ class Tiles:
     ncols: int
     idx: torch.Tensor        # int32 [items]  (slot << lw) | local column
     val: torch.Tensor        # float32 / float64 [items]
-    tile_ptr: torch.Tensor   # int32 [nblk*npanel + 1], item offsets, multiples of 256
+    tile_ptr: torch.Tensor   # int64 [nblk*npanel + 1], item offsets, multiples of 256
     cnt: torch.Tensor        # int32: 8*cw nibbles per (tile, thread), cw = 5 (f32) or 3 (f64), laid out for coalesced loads:
                              #   [tile][thread][4] (words 0..3, zero padded) then [tile][cw - 4][thread] (the other words)
     groups: int = 1          # workgroups sharing a row block (each walks ceil(npanel/groups) panels)
@@ -264,8 +264,8 @@ def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, n
     NB = max(1, (nrows + RB - 1) // RB)
     if cap + 4 > (1 << (32 - lw)) or cap > cap_max:
         raise ValueError("cap does not fit")
-    if nnz + GROUP * NB * P >= 2 ** 31:
-        return None
+    # (item positions are 64-bit in the library: no limit on the items of one matrix copy; a remainder above 2^31 - 1 items -- its
+    #  ranges are 32-bit -- cannot happen: max_rest stops a matrix that clustered long before)
     rp = rowptr.long()
     row_counts = rp[1:] - rp[:-1]
     parts_idx, parts_val, parts_cnt = [], [], []
@@ -323,7 +323,7 @@ def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, n
             if nd:
                 drop = ~keep
                 n_over += nd
-                if n_over > max_rest * nnz:
+                if n_over > max_rest * nnz or n_over >= 2 ** 31:
                     return None
                 over_row.append(rloc[drop] + r_lo)
                 over_col.append(cols[drop])
@@ -346,7 +346,7 @@ def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, n
     cat = lambda parts, dt: (parts[0] if len(parts) == 1 else torch.cat(parts)) if parts else torch.zeros(0, dtype=dt, device=dev)
     idx_all, val_all = cat(parts_idx, torch.int32), cat(parts_val, val.dtype)
     del parts_idx, parts_val
-    t = Tiles(lw, rpt, cap, NB, P, nrows, ncols, idx_all, val_all, tile_ptr.to(torch.int32), _count_layout(cat(parts_cnt, torch.int32), NB * P, CW),
+    t = Tiles(lw, rpt, cap, NB, P, nrows, ncols, idx_all, val_all, tile_ptr, _count_layout(cat(parts_cnt, torch.int32), NB * P, CW),
               normalize_groups(groups, P, max(1, int(max_groups))), rpt_max)
     t.stats = dict(nnz=nnz, tiled=nnz - n_over, remainder=0)
     if n_over == 0:
