@@ -153,6 +153,8 @@ int rccl_load(const char* path)
 // ------------------------------------------------------------------------------------------------
 struct Schedule {
     int64_t* blk = nullptr;   // device, nblk+1 pairs (first row, first non-zero)
+    uint32_t* rplo = nullptr; // device, rows+1: the LOW 32 bits of the row pointers.  Inside a row block the kernel only needs offsets relative
+                              // to the block's first non-zero (< 2^32 apart), so it reads 4 bytes per row instead of 8: (uint32)(rp[r]) - (uint32)a
     int nblk = 0;
     int grid = 0;
     // rows longer than NNZ_CAP, cut into chunks of NNZ_CAP non-zeros
@@ -386,7 +388,7 @@ int launch_mat(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* 
         HIP_TRY(hipGetLastError());
         return PDLP_OK;
     }
-    const int64_t* rp = transpose ? h->p.KT_rowptr : h->p.K_rowptr;
+    const uint32_t* rp = s.rplo;          // (low words of the row pointers: csr_pass needs block-relative offsets only)
     const int32_t* ci = transpose ? h->p.KT_colidx : h->p.K_colidx;
     const TV* va = (const TV*)(transpose ? h->p.KT_val : h->p.K_val);
     if (s.sidx)
@@ -1112,6 +1114,8 @@ int64_t layout(const pdlp_problem* p, int64_t nnzK, int64_t nnzKT, int64_t* offs
     const bool sharded = nl != p->n || ml != p->m;                // panel tables of the split products (sharded problems only)
     offs[k++] = c.take(sharded ? ((p->n >> 4) + 8) * 4 : 0);      // 40    panels of K by phase  (panel width >= 16 columns)
     offs[k++] = c.take(sharded ? ((p->m >> 4) + 8) * 4 : 0);      // 41    panels of K'
+    offs[k++] = c.take((ml + 1) * 4);                             // 42    low words of K's row pointers (the CSR kernel's 4-byte reads)
+    offs[k++] = c.take((nl + 1) * 4);                             // 43    ... of K''s
     return c.off;
 }
 
@@ -1239,6 +1243,16 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     h->graph_ok = side && std::getenv("PDLP_GRAPH") != nullptr;
     h->use_split = false;
 
+    h->sK.rplo = (uint32_t*)(w + offs[42]); h->sKT.rplo = (uint32_t*)(w + offs[43]);
+    {
+        std::vector<uint32_t> lo((size_t)(ml > nl ? ml : nl) + 1);
+        for (int64_t i = 0; i <= ml; ++i) lo[(size_t)i] = (uint32_t)rpK[(size_t)i];
+        if (hipMemcpyAsync(h->sK.rplo, lo.data(), (size_t)(ml + 1) * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) { free_handle(h); return PDLP_ERR_HIP_BASE - 1; }
+        for (int64_t i = 0; i <= nl; ++i) lo[(size_t)i] = (uint32_t)rpKT[(size_t)i];
+        if (hipMemcpyAsync(h->sKT.rplo, lo.data(), (size_t)(nl + 1) * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) { free_handle(h); return PDLP_ERR_HIP_BASE - 1; }
+    }
     std::vector<int64_t> sched;
     build_schedule_host(rpK, ml, sched);
     h->sK.nblk = ml > 0 ? (int)sched.size() / 2 - 1 : 0;
@@ -1271,7 +1285,7 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     }
     // zero every state vector, scratch and scalar (everything in front of the schedules)
     if (rc == PDLP_OK && hipMemsetAsync(w, 0, (size_t)offs[18], h->stream) != hipSuccess) rc = PDLP_ERR_HIP_BASE - 1;
-    if (rc == PDLP_OK && hipMemsetAsync(w + offs[29], 0, (size_t)(need - offs[29]), h->stream) != hipSuccess) rc = PDLP_ERR_HIP_BASE - 1;
+    if (rc == PDLP_OK && hipMemsetAsync(w + offs[29], 0, (size_t)(offs[42] - offs[29]), h->stream) != hipSuccess) rc = PDLP_ERR_HIP_BASE - 1;   // (42, 43: the row pointers' low words, uploaded above)
     if (rc != PDLP_OK) { free_handle(h); return rc; }
     if (p->dtype == PDLP_F32) hipLaunchKernelGGL(k_set_step<float>, dim3(1), dim3(1), 0, h->stream, h->sc, 0.0, 1.0, 1.0, 0.0);
     else hipLaunchKernelGGL(k_set_step<double>, dim3(1), dim3(1), 0, h->stream, h->sc, 0.0, 1.0, 1.0, 0.0);
