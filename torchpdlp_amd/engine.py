@@ -345,8 +345,11 @@ class PdlpEngine:
         th = threading.Thread(target=init, daemon=True)
         th.start()
         th.join(timeout)
+        if th.is_alive():
+            self._comm_init_thread = th          # poisoned: the handle is never destroyed while that thread lives (__del__)
         if not agree((not th.is_alive()) and res.get("rc") == 0):
-            log.append(f"init failed or timed out (this rank: alive={th.is_alive()}, rc={res.get('rc')})")
+            log.append(f"init failed or timed out (this rank: alive={th.is_alive()}, rc={res.get('rc')})"
+                       + ("; the handle is poisoned (a thread is still inside pdlp_comm_init): end this process rather than reuse it" if th.is_alive() else ""))
             return False
         # round trip: all-gather of a full-length vector and the 8-double all-reduce (rank-local errors are caught, so that
         # every rank reaches the agreement below)
@@ -516,6 +519,12 @@ class PdlpEngine:
 
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
+        th = getattr(self, "_comm_init_thread", None)
+        if h and th is not None and th.is_alive():
+            # a pdlp_comm_init that timed out is still inside ncclCommInitRank with this handle: destroying it now would race with
+            # that thread (it may yet write the communicator, the stream and the events).  The handle is leaked on purpose; the
+            # owner should end the process (bench.py does) rather than reuse it.
+            return
         if h:
             self.lib.pdlp_destroy(h)
 
