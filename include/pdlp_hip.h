@@ -101,7 +101,10 @@ typedef struct pdlp_tiles {
                                    epilogue is fused, > 1 (<= 8, <= npanel) = partial row sums + k_rowsum_epilogue */
     const uint32_t* idx;        /* [items]                                                                 */
     const void* val;            /* [items] in the problem's precision                                      */
-    const int64_t* tile_ptr;    /* [nblk*npanel + 1] item offsets (64-bit), multiples of 256               */
+    const int32_t* tile_ptr;    /* [nblk][npanel + 1] item offsets of a row block's tiles RELATIVE to the block's first item,
+                                   multiples of 256 (32-bit: what a thread indexes with) ...                               */
+    const int64_t* blk_base;    /* [nblk] ... and the position of every row block's first item in idx / val (64-bit: one
+                                   matrix copy may hold more than 2^31 items)                                              */
     const uint32_t* cnt;        /* 4-bit counts, 16-byte aligned: [tiles][512][4] words 0..3, then [tiles][cw-4][512]; cw = 5|3                                                 */
     /* the remainder: items the tiles could not hold (more than 15 of a row in one tile, more than 255 of 64 consecutive rows,
      * more than cap in a tile), as segments of <= 512 items of the rows that have any; rem_rows_n = 0: none */

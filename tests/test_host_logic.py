@@ -237,7 +237,7 @@ def test_bench_command_line_contract(monkeypatch):
 
 def test_offsets_are_64_bit_end_to_end():
     """VERDICT r3 (missing 4): one handle may hold more than 2^31 - 1 non-zeros per matrix copy.  Row pointers are int64 from the
-    host arrays to the C ABI (include/pdlp_hip.h: K_rowptr, KT_rowptr, tile_ptr, the schedule), column indices stay int32."""
+    host arrays to the C ABI (include/pdlp_hip.h: K_rowptr, KT_rowptr, the tiles' row-block bases, the schedule), column indices stay int32."""
     import os, re, torch
     from torchpdlp_amd.sparse import CsrPair, _counts_to_rowptr
     rp = _counts_to_rowptr(torch.tensor([2 ** 31, 2 ** 31, 5], dtype=torch.int64))
@@ -246,7 +246,7 @@ def test_offsets_are_64_bit_end_to_end():
     assert K.rowptr.dtype == K.t_rowptr.dtype == torch.int64 and K.colidx.dtype == K.t_colidx.dtype == torch.int32
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hdr = open(os.path.join(root, "include", "pdlp_hip.h")).read()
-    for field in ("K_rowptr", "KT_rowptr", "tile_ptr"):
+    for field in ("K_rowptr", "KT_rowptr", "blk_base"):          # (tile offsets are 32-bit relative to their row block's 64-bit base)
         assert re.search(r"const int64_t\*\s+" + field + ";", hdr), field
     assert "const int64_t** blocks" in hdr
 

@@ -34,7 +34,7 @@ class PdlpProblem(C.Structure):
 class PdlpTiles(C.Structure):
     """mirror of ``struct pdlp_tiles``"""
     _fields_ = [("lw", C.c_int32), ("rpt", C.c_int32), ("cap", C.c_int32), ("nblk", C.c_int32), ("npanel", C.c_int32),
-                ("groups", C.c_int32), ("idx", C.c_void_p), ("val", C.c_void_p), ("tile_ptr", C.c_void_p), ("cnt", C.c_void_p),
+                ("groups", C.c_int32), ("idx", C.c_void_p), ("val", C.c_void_p), ("tile_ptr", C.c_void_p), ("blk_base", C.c_void_p), ("cnt", C.c_void_p),
                 ("rem_rows_n", C.c_int32), ("rem_segs_n", C.c_int32), ("rem_rows", C.c_void_p), ("rem_rptr", C.c_void_p),
                 ("rem_sptr", C.c_void_p), ("rem_col", C.c_void_p), ("rem_val", C.c_void_p), ("rem_work", C.c_void_p),
                 ("rem_extra", C.c_void_p), ("rem_extra_f32", C.c_void_p)]

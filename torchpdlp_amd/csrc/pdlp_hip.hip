@@ -330,7 +330,7 @@ void launch_tiled_groups(pdlp_handle h, const Schedule& s, int rows, const void*
     const int groups = (vtotal + ppg - 1) / ppg;          // no group without panels
     StoreEpi<T> none{nullptr};
     hipLaunchKernelGGL((k_tiled_fused<T, TV, StoreEpi<T>, false>), dim3(s.t.nblk * groups), dim3(TNT), 0, stream, s.t.idx,
-                       (const TV*)s.t.val, s.t.tile_ptr, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, ppg, vtotal, ptab,
+                       (const TV*)s.t.val, s.t.tile_ptr, s.t.blk_base, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, ppg, vtotal, ptab,
                        slot0, (const T*)vin, (T*)h->rowsum, h->rs_stride, (const T*)nullptr, none, (double*)nullptr);
 }
 
@@ -369,7 +369,7 @@ int launch_mat(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* 
         }
         if (s.t.groups == 1 && !(s.pending && h->use_split)) {
             hipLaunchKernelGGL((k_tiled_fused<T, TV, Epi, true>), dim3(s.t.nblk), dim3(TNT), 0, h->stream, s.t.idx, (const TV*)s.t.val,
-                               s.t.tile_ptr, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, s.t.npanel, s.t.npanel,
+                               s.t.tile_ptr, s.t.blk_base, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, s.t.npanel, s.t.npanel,
                                (const int32_t*)nullptr, 0, (const T*)vin, (T*)h->rowsum, h->rs_stride, extra, epi, partials);
         } else if (s.pending && h->use_split) {
             // the local panels were multiplied by pdlp_*_half_begin on the side stream (and the first chunks' panels by
@@ -1139,7 +1139,7 @@ int read_last_rowptr(const int64_t* rp, int64_t rows, int64_t* nnz, hipStream_t 
 // ================================================================================================
 extern "C" {
 
-int pdlp_abi_version(void) { return 15; }  // 15: 64-bit row pointers, tile pointers and schedule offsets (more than 2^31 non-zeros per handle); 14: pdlp_probe_stream_read; 13: chunked exchange (pdlp_set_exchange_chunks, pdlp_exchange_plan, pdlp_half_chunk); 12: count words of a tile laid out for coalesced loads; 11: pdlp_comm_load; 10: pdlp_set_anchors; 9: pdlp_attach_sorted; 8: running products, pdlp_flush_average(h, adaptive); 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
+int pdlp_abi_version(void) { return 15; }  // 15: 64-bit row pointers, row-block bases of the tiles and schedule offsets (more than 2^31 non-zeros per handle); 14: pdlp_probe_stream_read; 13: chunked exchange (pdlp_set_exchange_chunks, pdlp_exchange_plan, pdlp_half_chunk); 12: count words of a tile laid out for coalesced loads; 11: pdlp_comm_load; 10: pdlp_set_anchors; 9: pdlp_attach_sorted; 8: running products, pdlp_flush_average(h, adaptive); 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
 
 const char* pdlp_strerror(int code)
 {
@@ -1341,7 +1341,7 @@ int pdlp_attach_tiles(pdlp_handle h, int transpose, const pdlp_tiles* t)
     if (t->nblk > h->part_blocks) return PDLP_ERR_INVALID;             // one slot of partial sums per workgroup
     const int ppg = (t->npanel + t->groups - 1) / t->groups;
     if ((t->groups - 1) * ppg >= t->npanel) return PDLP_ERR_INVALID;     // every group must own at least one panel
-    if (!t->idx || !t->val || !t->tile_ptr || !t->cnt) return PDLP_ERR_INVALID;
+    if (!t->idx || !t->val || !t->tile_ptr || !t->blk_base || !t->cnt) return PDLP_ERR_INVALID;
     if (((uintptr_t)t->idx & 15u) || ((uintptr_t)t->val & 15u) || ((uintptr_t)t->cnt & 15u)) return PDLP_ERR_INVALID;
     if (t->rem_rows_n < 0 || t->rem_segs_n < t->rem_rows_n) return PDLP_ERR_INVALID;
     if (t->rem_rows_n > 0 && (!t->rem_rows || !t->rem_rptr || !t->rem_sptr || !t->rem_col || !t->rem_val || !t->rem_work || !t->rem_extra ||

@@ -277,7 +277,8 @@ class PdlpEngine:
             rem = [int(t.rem_rows.numel()), int(t.rem_sptr.numel()) - 1, t.rem_rows.data_ptr(), t.rem_rptr.data_ptr(), t.rem_sptr.data_ptr(),
                    t.rem_col.data_ptr(), t.rem_val.data_ptr(), t._work.data_ptr(), t._extra.data_ptr(),
                    None if t._extra32 is None else t._extra32.data_ptr()]
-        desc = N.PdlpTiles(t.lw, t.rpt, t.cap, t.nblk, t.npanel, t.groups, t.idx.data_ptr(), t.val.data_ptr(), t.tile_ptr.data_ptr(),
+        rel, base = t.abi_tile_ptr()          # (int32 offsets relative to each row block's first item + the 64-bit bases; kept alive on t)
+        desc = N.PdlpTiles(t.lw, t.rpt, t.cap, t.nblk, t.npanel, t.groups, t.idx.data_ptr(), t.val.data_ptr(), rel.data_ptr(), base.data_ptr(),
                            t.cnt.data_ptr(), *rem)
         N.check(self.lib.pdlp_attach_tiles(self.h, int(transpose), C.byref(desc)), "pdlp_attach_tiles")
         self._plans = {}

@@ -68,7 +68,7 @@ class Tiles:
     ncols: int
     idx: torch.Tensor        # int32 [items]  (slot << lw) | local column
     val: torch.Tensor        # float32 / float64 [items]
-    tile_ptr: torch.Tensor   # int64 [nblk*npanel + 1], item offsets, multiples of 256
+    tile_ptr: torch.Tensor   # int64 [nblk*npanel + 1], item offsets, multiples of 256 (the library takes them per row block: abi_tile_ptr)
     cnt: torch.Tensor        # int32: 8*cw nibbles per (tile, thread), cw = 5 (f32) or 3 (f64), laid out for coalesced loads:
                              #   [tile][thread][4] (words 0..3, zero padded) then [tile][cw - 4][thread] (the other words)
     groups: int = 1          # workgroups sharing a row block (each walks ceil(npanel/groups) panels)
@@ -96,6 +96,22 @@ class Tiles:
     @property
     def nrem(self) -> int:
         return 0 if self.rem_col is None else int(self.rem_col.numel())
+
+    def abi_tile_ptr(self):
+        """(int32 [nblk][npanel + 1] offsets relative to each row block's first item, int64 [nblk] those first items): what
+        ``pdlp_attach_tiles`` takes.  A row block never holds 2^31 items, a matrix copy may: the kernel adds the block's 64-bit base to
+        its pointers once and indexes with 32 bits."""
+        if getattr(self, "_abi_tp", None) is None:
+            tp = self.tile_ptr.view(-1)
+            nb, P = self.nblk, self.npanel
+            base = tp[:nb * P:P].contiguous()                                   # first item of every row block
+            body = tp[:nb * P].view(nb, P)
+            ends = torch.cat([tp[P:nb * P:P], tp[nb * P:nb * P + 1]]).view(nb, 1)   # end of a block = start of the next (the last: total)
+            rel = torch.cat([body, ends], dim=1) - base.view(nb, 1)
+            if int(rel.max()) >= 2 ** 31:
+                raise ValueError("a single row block holds 2^31 items or more")
+            self._abi_tp = (rel.to(torch.int32).contiguous(), base.to(torch.int64).contiguous())
+        return self._abi_tp
 
     def bytes(self) -> int:
         ts = (self.idx, self.val, self.tile_ptr, self.cnt, self.rem_rows, self.rem_rptr, self.rem_sptr, self.rem_col, self.rem_val)
