@@ -372,6 +372,74 @@ def exchange_phases(eng, comm, roofline, ms_per_iteration, reps: int = 10) -> di
                 note="each part timed alone (max over ranks); exposed = iteration - the two fused products")
 
 
+class Deadman:
+    """A phase of a multi-rank run that may hang (first contact with a second RCCL communicator, a solve over it, a teardown) must not
+    cost the line that was measured before it: ``arm(seconds, line_fn, why)`` starts a timer that -- unless ``disarm()`` comes first --
+    prints ``line_fn()`` from rank 0 and ends this rank's process with exit code 0.  A process with a thread stuck inside RCCL is
+    poisoned; nothing of it is reused or destroyed."""
+
+    def __init__(self, rank: int):
+        import threading
+        self.rank, self._threading, self._ev = rank, threading, None
+
+    def arm(self, seconds: float, line_fn, why: str):
+        self.disarm()
+        ev = self._ev = self._threading.Event()
+        rank = self.rank
+
+        def run():
+            if not ev.wait(seconds):
+                try:
+                    line = line_fn()
+                except Exception:
+                    line = None
+                if rank == 0 and line:
+                    print(line, flush=True)
+                sys.stderr.write(f"bench.py: rank {rank}: {why} (no progress for {seconds:.0f} s); leaving with the line already measured\n")
+                sys.stderr.flush()
+                os._exit(0)
+        self._threading.Thread(target=run, daemon=True).start()
+
+    def disarm(self):
+        if self._ev is not None:
+            self._ev.set()
+            self._ev = None
+
+
+def library_phase(out: dict, exchange: dict, eng, steps: int, timed_region, norm_elapsed: float, rank: int, limit: float = 90.0,
+                  slack: float = 120.0):
+    """N > 1 under RCCL, AFTER the headline was measured on the torch.distributed loop: try the library's own communicator (one C call
+    per restart period), cross-checked bit for bit against that loop, and repeat the timed region on it.  Whatever happens in here --
+    a hang inside ncclCommInitRank included -- the line already measured is what gets printed.  Every decision uses numbers that are
+    maxima over the ranks, so all ranks take the same branch."""
+    snapshot = json.dumps(dict(out, config=dict(out["config"], exchange=dict(
+        exchange, path=f"torch.distributed loop (library path abandoned by the watchdog after {2 * limit + slack:.0f} s)"))))
+    deadman = Deadman(rank)
+    deadman.arm(2 * limit + slack, lambda: snapshot, "the library communicator phase hung")
+    try:
+        on = eng.enable_library_comm(timeout=limit, cross_check=True)
+        exchange["log"] = list(getattr(eng, "lib_comm_log", []))
+        if on:
+            reg2 = timed_region()
+            v1, v2 = steps / norm_elapsed, steps / reg2["norm_elapsed"]
+            exchange["torch_loop_value"], exchange["library_value"] = round(v1, 3), round(v2, 3)
+            if v2 >= v1:
+                exchange["path"] = "library RCCL communicator (pdlp_iterate)"
+                out["value"], out["ms_per_step"] = round(v2, 3), round(reg2["norm_elapsed"] / steps * 1e3, 4)
+                out["timing"].update(elapsed_s=round(reg2["elapsed"], 6), raw_value=round(steps / reg2["elapsed"], 3),
+                                     checks_in_timed_region=reg2["checks_in"], restarts_in_timed_region=reg2["restarts_in"],
+                                     check_ms=round(reg2["check_s"] * 1e3, 3), normalised_elapsed_s=round(reg2["norm_elapsed"], 6))
+            else:
+                exchange["path"] = "torch.distributed loop (library path works and is bit-identical, but was slower here)"
+                eng.lib_comm = False
+        else:
+            exchange["path"] = "torch.distributed loop (library path declined)"
+    except Exception as e:
+        exchange["path"] = f"torch.distributed loop (library path failed: {type(e).__name__})"
+        eng.lib_comm = False
+    deadman.disarm()
+
+
 def _imports():
     """torch and the package, only in a process that is going to compute (after the decision to spawn ranks)"""
     global torch, tp, N, PdhgDriver, estimate_sigma
@@ -557,46 +625,13 @@ def main(argv=None):
             # on a second stream -- has only ever run against the test stand-in, and a first contact belongs outside a benchmark)
             exchange["path"] = "torch.distributed loop (chunked exchange: library driver not tried)"
         elif args.lib_comm == "auto" and comm.backend == "nccl":
-            # The library's own RCCL communicator (one C call per restart period), cross-checked bit for bit against the loop just
-            # measured.  Whatever happens in here -- a hang in ncclCommInitRank included -- the line measured above is what gets
-            # printed: the watchdog prints it from rank 0 and ends every rank's process (a process with a stuck RCCL thread is
-            # poisoned; nothing of it is reused or destroyed).
-            import threading
-            limit = float(os.environ.get("PDLP_COMM_TIMEOUT", "90"))
-            fallback = json.dumps(dict(out, config=dict(out["config"], exchange=dict(
-                exchange, path=f"torch.distributed loop (library path abandoned by the watchdog after {2 * limit + 120:.0f} s)"))))
-            finished = threading.Event()
-
-            def watchdog():
-                if not finished.wait(2 * limit + 120):
-                    if rank == 0:
-                        print(fallback, flush=True)
-                    sys.stderr.write(f"bench.py: rank {rank}: library communicator phase hung; leaving with the torch.distributed line\n")
-                    sys.stderr.flush()
-                    os._exit(0)
-            threading.Thread(target=watchdog, daemon=True).start()
-            try:
-                on = eng.enable_library_comm(timeout=limit, cross_check=True)
-                exchange["log"] = eng.lib_comm_log
-                if on:
-                    reg2 = timed_region()
-                    v1, v2 = args.steps / norm_elapsed, args.steps / reg2["norm_elapsed"]
-                    exchange["torch_loop_value"], exchange["library_value"] = round(v1, 3), round(v2, 3)
-                    if v2 >= v1:
-                        exchange["path"] = "library RCCL communicator (pdlp_iterate)"
-                        out["value"], out["ms_per_step"] = round(v2, 3), round(reg2["norm_elapsed"] / args.steps * 1e3, 4)
-                        out["timing"].update(elapsed_s=round(reg2["elapsed"], 6), raw_value=round(args.steps / reg2["elapsed"], 3),
-                                             checks_in_timed_region=reg2["checks_in"], restarts_in_timed_region=reg2["restarts_in"],
-                                             check_ms=round(reg2["check_s"] * 1e3, 3), normalised_elapsed_s=round(reg2["norm_elapsed"], 6))
-                    else:
-                        exchange["path"] = "torch.distributed loop (library path works and is bit-identical, but was slower here)"
-                        eng.lib_comm = False
-                else:
-                    exchange["path"] = "torch.distributed loop (library path declined)"
-            except Exception as e:
-                exchange["path"] = f"torch.distributed loop (library path failed: {type(e).__name__})"
-                eng.lib_comm = False
-            finished.set()
+            library_phase(out, exchange, eng, args.steps, timed_region, norm_elapsed, rank,
+                          limit=float(os.environ.get("PDLP_COMM_TIMEOUT", "90")))
+    # from here on (time to tolerance, teardown of the communicators) a hang must not cost the line either
+    deadman = Deadman(rank)
+    if comm is not None:
+        deadman.arm(args.solve_limit + 600.0, lambda: json.dumps(dict(out, time_to_tol={"error": "abandoned by the watchdog"})),
+                    "the phases after the timed region hung")
     if args.solve_tol > 0:
         # time to tolerance (untimed part of the run, the engine of the timed region re-started from zero): the reference's default
         # tolerance fits a bench run; tighter ones are separate runs (tools/time_to_tol.py), recorded in profiles/time_to_tol.json
@@ -620,9 +655,12 @@ def main(argv=None):
             out["cpu_baseline"] = cpu_baseline(args, torch.float64 if args.dtype != "f32" else dt)
         except Exception as e:
             out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    deadman.disarm()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if comm is not None:
+        # (teardown: the line is out; a rank stuck in here is the launcher's business -- spawn_ranks relays the line and stops the
+        # ranks after its grace period, torch.distributed.run has its own timeouts)
         comm.dist.barrier()
         comm.dist.destroy_process_group()
     return 0

@@ -138,3 +138,80 @@ def test_gpus_defaults_to_the_launchers_world_size(monkeypatch):
     with pytest.raises(RuntimeError, match="compute part"):          # neither: one rank, in this process
         bench.main(["--steps", "1"])
     assert seen == {}
+
+
+# ---------------------------------------------------------------------------------------------------
+# the library-communicator phase of a multi-rank run (first contact with a second RCCL communicator): whatever it does, the line that
+# was measured on the torch.distributed loop before it is what comes out
+# ---------------------------------------------------------------------------------------------------
+class _Eng:
+    lib_comm = None
+    lib_comm_log = ["log line"]
+
+    def __init__(self, behaviour):
+        self.behaviour = behaviour
+
+    def enable_library_comm(self, timeout, cross_check):
+        assert cross_check
+        if self.behaviour == "raise":
+            raise RuntimeError("boom")
+        self.lib_comm = self.behaviour == "on"
+        return self.behaviour == "on"
+
+
+def _line():
+    return {"metric": "PDHG iterations/sec", "value": 100.0, "ms_per_step": 10.0, "config": {"workload": "w"}, "timing": {"elapsed_s": 0.2}}
+
+
+def _region(norm):
+    return lambda: dict(norm_elapsed=norm, elapsed=norm, checks_in=0, restarts_in=0, check_s=0.001)
+
+
+def test_library_phase_outcomes():
+    for behaviour, norm2, want_path, want_value in (("off", None, "declined", 100.0), ("raise", None, "failed: RuntimeError", 100.0),
+                                                    ("on", 0.1, "library RCCL communicator", 200.0), ("on", 0.4, "slower here", 100.0)):
+        out, ex, eng = _line(), {"path": "torch.distributed loop"}, _Eng(behaviour)
+        bench.library_phase(out, ex, eng, 20, _region(norm2), 0.2, rank=0, limit=0.5, slack=0.5)
+        assert want_path in ex["path"], (behaviour, ex)
+        assert out["value"] == want_value
+        if behaviour == "on":
+            assert ex["torch_loop_value"] == 100.0 and ex["library_value"] == round(20 / norm2, 3) and ex["log"] == ["log line"]
+            assert eng.lib_comm == (norm2 < 0.2)              # the slower driver is switched off again on every rank
+        if behaviour == "raise":
+            assert eng.lib_comm is False
+
+
+def test_a_hung_library_phase_still_prints_the_measured_line(tmp_path):
+    """a rank stuck inside ncclCommInitRank: the watchdog prints the torch.distributed line from rank 0 and ends the process, exit 0"""
+    import subprocess
+    script = _script(tmp_path, f"""
+        import sys, time, json
+        sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+        import bench
+
+        class Eng:
+            lib_comm_log = []
+            def enable_library_comm(self, timeout, cross_check):
+                time.sleep(600)
+        out = {{"metric": "PDHG iterations/sec", "value": 123.0, "config": {{"workload": "w"}}, "timing": {{}}}}
+        bench.library_phase(out, {{"path": "torch.distributed loop"}}, Eng(), 20, None, 0.2, rank=int(sys.argv[1]), limit=0.3, slack=0.4)
+        print("not reached")
+    """)
+    for rank, want_line in ((0, True), (1, False)):
+        r = subprocess.run([sys.executable, script, str(rank)], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and "not reached" not in r.stdout and "hung" in r.stderr
+        if want_line:
+            d = json.loads(r.stdout.strip())
+            assert d["value"] == 123.0 and "abandoned by the watchdog" in d["config"]["exchange"]["path"]
+        else:
+            assert r.stdout.strip() == ""
+
+
+def test_deadman_can_be_disarmed(capfd):
+    import time
+    dm = bench.Deadman(0)
+    dm.arm(0.2, lambda: "never printed", "test")
+    dm.disarm()
+    time.sleep(0.5)
+    out, _ = capfd.readouterr()
+    assert out == ""
