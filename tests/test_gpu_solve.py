@@ -349,3 +349,34 @@ def test_mixed_precision_with_ruiz_on_a_plus_minus_one_matrix():
     r = torch.zeros(lp.m, dtype=torch.float64, device="cuda:0").index_add_(0, rows, K.val * xs[lp.colidx.long()]) - q
     r[:lp.m_ineq].clamp_(max=0)
     assert float(r.norm()) <= 2e-6 * (1 + float(q.norm()))
+
+
+@pytest.mark.gpu
+def test_bench_line_contract_on_a_small_workload():
+    """bench.py's one JSON line (the driver's contract): metric / value / unit / n_gpus / steps / warmup / ms_per_step / scaling / dtype /
+    data / config.workload, the roofline object measured live (bound, achieved, peak, frac, traffic key, the kernel's launch time), the
+    cpu_baseline object (value, cores, kind, sample) and the time-to-tolerance record -- on a 300k x 300k LP so that it takes seconds.
+    The line is the LAST line of stdout and the only one that parses as JSON."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PDLP_BENCH_N="300000", PDLP_BENCH_NNZ="20")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "40", "--warmup", "5", "--cpu-sample-rows", "100000",
+                        "--solve-limit", "30"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    d = json.loads(lines[-1])
+    assert sum(1 for ln in lines if ln.lstrip().startswith("{")) == 1
+    assert d["metric"] == "PDHG iterations/sec" and d["unit"] == "iterations/s" and d["higher_is_better"] is True
+    assert (d["n_gpus"], d["steps"], d["warmup"]) == (1, 40, 5) and d["data"] == "synthetic" and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert d["value"] > 0 and abs(d["ms_per_step"] * d["value"] - 1000.0) < 1.0
+    assert "300000x300000" in d["config"]["workload"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and "traffic" in rf
+    assert rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["launch_ms"] > 0 and rf["algorithmic_bytes"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "oracle" in cb["sample"] and cb["machine_cores"] >= cb["cores"]
+    assert d["time_to_tol"]["tol"] == 1e-4 and d["time_to_tol"]["status"] in ("Solved", "Unsolved (time limit exceeded)")
+    assert d["timing"]["checks_in_timed_region"] == 1
