@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("PDLP_LIB", os.path.join(_HERE, "libpdlp_hip.so"))   # PDLP_LIB: profiling/ablation builds
+LIB_PATH = os.environ.get("PDLP_LIB") or os.path.join(_HERE, "libpdlp_hip.so")   # PDLP_LIB: profiling/ablation builds (empty = unset)
 
 ABI_VERSION = 15
 PDLP_F32, PDLP_F64, PDLP_MIXED = 0, 1, 2
