@@ -72,10 +72,10 @@ __global__ __launch_bounds__(512, 4) void k_sg(const u32x4* __restrict__ idx, co
     if (acc == 123.456f) out[0] = acc;
 }
 
-template <int MODE, int RIF, int WINB> void run(const char* name, const u32x4* idx, const f32x4* val, const float* table, size_t n16, float* out, int grid)
+template <int MODE, int RIF, int WINB> void run(const char* name, const u32x4* idx, const f32x4* val, const float* table, size_t n16, float* out, int grid, int lds_pad = 0)
 {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const int ldsb = MODE ? 8 * RIF * WINB : 0;
+    const int ldsb = lds_pad ? lds_pad : (MODE ? 8 * RIF * WINB : 0);       // (lds_pad: 100 KB forces one workgroup per CU)
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sg<MODE, RIF, WINB>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb > 0 ? ldsb : 16));
     for (int w = 0; w < 2; ++w) k_sg<MODE, RIF, WINB><<<grid, 512, ldsb>>>(idx, val, table, n16, out);
     CHECK(hipGetLastError());
@@ -98,6 +98,8 @@ int main()
         k_fill_idx<<<4096, 256>>>(idx, items, sp10);
         CHECK(hipDeviceSynchronize());
         printf("--- sorted neighbours %.1f columns apart (%s)\n", sp10 / 10.0, sp10 == 50 ? "the bench tiles: 19 968 rows per workgroup" : "39 936 rows per workgroup");
+        run<0, 4, 2048>("TA gathers, ONE workgroup (8 waves) per CU", (const u32x4*)idx, (const f32x4*)val, table, n16, out, 256, 100 * 1024);
+        run<0, 4, 2048>("TA gathers, ONE workgroup per CU, 2 rounds", (const u32x4*)idx, (const f32x4*)val, table, n16, out, 512, 100 * 1024);
         for (int grid : {512, 1024}) {
             run<0, 4, 2048>("TA gathers, 4 per lane in flight", (const u32x4*)idx, (const f32x4*)val, table, n16, out, grid);
             run<1, 1, 2048>("windows in LDS", (const u32x4*)idx, (const f32x4*)val, table, n16, out, grid);
