@@ -164,3 +164,18 @@ def test_chosen_groups_fit_the_rowsum_scratch():
                     assert 1 <= groups <= lim and 1 <= rpt <= rpt_max
                     P = max(1, (cols + (1 << lw) - 1) >> lw)
                     assert T.normalize_groups(groups, P, min(8, lim)) == groups
+
+
+def test_abi_tile_ptr_is_relative_to_64_bit_row_block_bases():
+    """ABI 15: the library takes the tile offsets per row block -- int32 [nblk][npanel + 1] relative to the block's first item plus an
+    int64 base per block -- so that a thread indexes with 32 bits while a matrix copy may hold more than 2^31 items"""
+    tp = torch.tensor([0, 256, 512, 512, 1024, 1280, 1280, 2048, 2304], dtype=torch.int64)          # 2 row blocks x 4 panels
+    t = T.Tiles(6, 1, 16384, 2, 4, 10, 10, torch.zeros(1, dtype=torch.int32), torch.zeros(1), tp, torch.zeros(1, dtype=torch.int32))
+    rel, base = t.abi_tile_ptr()
+    assert rel.dtype == torch.int32 and base.dtype == torch.int64
+    assert rel.tolist() == [[0, 256, 512, 512, 1024], [0, 256, 256, 1024, 1280]] and base.tolist() == [0, 1024]
+    assert t.abi_tile_ptr()[0] is rel                                   # built once, kept alive with the tiles
+    big = tp + (1 << 33)                                                # positions far beyond 32 bits: only the bases grow
+    t2 = T.Tiles(6, 1, 16384, 2, 4, 10, 10, torch.zeros(1, dtype=torch.int32), torch.zeros(1), big, torch.zeros(1, dtype=torch.int32))
+    rel2, base2 = t2.abi_tile_ptr()
+    assert torch.equal(rel2, rel) and base2.tolist() == [1 << 33, (1 << 33) + 1024]
