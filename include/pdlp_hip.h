@@ -223,6 +223,16 @@ int pdlp_fixed_advance(pdlp_handle h, int iters);
  * pdlp_half_chunk does nothing.  pdlp_iterate on a handle with a communicator does all of this itself (pieces as grouped
  * in-place broadcasts on a communication stream of its own). */
 int pdlp_set_exchange_chunks(pdlp_handle h, int chunks /* 1..4 */);
+/* Switches of the handle that tests and tools flip (the library itself reads no environment variables; the Python host layer maps
+ * its PDLP_* test knobs onto these).  None has a counterpart in the reference; the defaults are the product path.
+ *   PDLP_OPT_RUNNING_KKT  1 (default): restart checks take K x_avg, K'y_avg from running sums (pdhg.py:118-125 costs one product
+ *                         instead of four); 0: every KKT pass multiplies
+ *   PDLP_OPT_KTY_REUSE    1 (default): the first primal half-step after a restart check reuses the check's K'y; 0: multiplies again
+ *   PDLP_OPT_GRAPH        0 (default) / 1: pdlp_iterate replays captured pairs of iterations as hipGraph launches (single-rank handles;
+ *                         PDLP_ERR_STATE when the handle cannot capture)
+ *   PDLP_OPT_SPLIT_SLOTS  0 (default): the library's rule; local | other << 16: panel groups of a split product (tools/split_timing.py) */
+enum { PDLP_OPT_RUNNING_KKT = 0, PDLP_OPT_KTY_REUSE = 1, PDLP_OPT_GRAPH = 2, PDLP_OPT_SPLIT_SLOTS = 3 };
+int pdlp_set_option(pdlp_handle h, int option, int64_t value);
 int pdlp_exchange_plan(pdlp_handle h, int transpose, int32_t* nchunks, int64_t bounds[5]);
 int pdlp_half_chunk(pdlp_handle h, int transpose, int chunk);
 int pdlp_comm_load(const char* rccl_path);
@@ -313,6 +323,11 @@ int pdlp_infeas_finish(pdlp_handle h, double tol, int32_t* status, double diag[8
  *   spectral_casting.py:215-234.  work: 256 * nvp * 4 + nvp * 4 doubles.  gaps: host array of nvp.  Synchronises. */
 int pdlp_mv_steps(pdlp_handle h, int nvp, int steps, double eta, double omega, double theta, void* X, void* Y, void* work);
 int pdlp_mv_gap(pdlp_handle h, int nvp, const void* X, const void* Y, void* work, double* gaps);
+/* pdlp_mv_product: Y = K X for all nvp points in one pass over K -- `pts_y = K @ pts` spectral_casting.py:100.
+ * pdlp_mv_combine: OUT[r][t] = sum_p V[r][p] * W[p][t] for t < nw -- the random convex combinations of the breeding rounds,
+ *   `new_x = pts @ w` spectral_casting.py:133-141 (V is [rows][j] row-major, W [j][nw], OUT [rows][nw]; j <= 32; no handle). */
+int pdlp_mv_product(pdlp_handle h, int nvp, const void* X, void* Y);
+int pdlp_mv_combine(int dtype, int64_t rows, int j, const void* V, const void* W, int nw, void* OUT, void* stream);
 
 /* ---- plain products (power iteration helpers.py:41-51, tests) ------------------------------- */
 /* out_local = K in_full (transpose=0, out has row1-row0 values) or K' in_full (transpose=1) */
@@ -342,6 +357,9 @@ int pdlp_vec_muldiv(int dtype, int64_t len, void* a, const void* b, int op, void
 int pdlp_vec_project_lambda(int dtype, int64_t len, const void* g, const void* l, const void* u, void* out, void* stream);
 /* max_i |1 - v[i]| (the early-exit test :60-61); host result, synchronises */
 int pdlp_vec_max_dev_from_one(int dtype, int64_t len, const void* v, void* work8, double* out, void* stream);
+/* sum_i (a[i] - b[i])^2, accumulated in double: the two distances of primal_weight_update (enhancements.py:74-75) for the
+ * reference-named operator (inside the solver: pdlp_restart_distance_local).  work: 1040 doubles; host result, synchronises */
+int pdlp_vec_sqdist(int dtype, int64_t len, const void* a, const void* b, void* work, double* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -2,7 +2,7 @@
 """One rank's shard of the bench problem on ONE GPU: how long a dual half-step takes when its product is split into
 "local panels first (side stream), the others after the all-gather" versus unsplit, with a spin kernel of the
 all-gather's duration standing in for the collective.  Used to choose the panel-group counts of the split.
-env: WORLD (8), AG_MS (0.1), SLOTS ("a,b" overrides the library's choice via PDLP_SPLIT_SLOTS), N, K,
+env: WORLD (8), AG_MS (0.1), SLOTS ("a,b" overrides the library's choice: pdlp_set_option(PDLP_OPT_SPLIT_SLOTS)), N, K,
 CHUNKS ("1,2,4": also time the chunked exchange -- the stand-in then runs as that many spin kernels on a second stream, each a
 1/chunks of AG_MS, and the panels a piece completes are launched when its spin kernel is done)"""
 import os, sys, time
@@ -38,6 +38,9 @@ nk = n // W            # K' block: one entry per row, only there to make a valid
 empty_kt = (torch.arange(0, nk + 1, dtype=torch.int32, device=dev), torch.randint(0, n, (nk,), generator=g, device=dev, dtype=torch.int32),
             torch.rand(nk, device=dev, generator=g))
 eng = tp.PdlpEngine(n, n, 0, (rp, col, val), empty_kt, zn, zm, zn, zn, rows=(0, m), cols=(0, n // W), comm=FakeComm())
+if os.environ.get("SLOTS"):
+    sa, sb = (int(v) for v in os.environ["SLOTS"].split(","))
+    eng.set_option(N_.OPT_SPLIT_SLOTS, sa | (sb << 16))
 print("tiles", [t is not None and (t.rpt, t.groups, t.nblk) for t in eng.tiles], "split", eng.split_info(0), flush=True)
 eng.set_step(0.01, 1.0, 1.0, 0)
 lib, h = eng.lib, eng.h

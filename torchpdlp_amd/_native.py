@@ -11,12 +11,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PDLP_LIB") or os.path.join(_HERE, "libpdlp_hip.so")   # PDLP_LIB: profiling/ablation builds (empty = unset)
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 PDLP_F32, PDLP_F64, PDLP_MIXED = 0, 1, 2
 CUR, AVG, PREV = 0, 1, 2
 (BUF_X_CUR, BUF_X_PREV, BUF_XBAR, BUF_X_AVG, BUF_Y_CUR, BUF_Y_PREV, BUF_Y_AVG, BUF_RED, BUF_X_SUM, BUF_Y_SUM,
  BUF_SCALARS, BUF_DX, BUF_DY, BUF_LAM_PREV, BUF_GDX, BUF_GDY) = range(16)
 NRED, NSCAL = 8, 16
+OPT_RUNNING_KKT, OPT_KTY_REUSE, OPT_GRAPH, OPT_SPLIT_SLOTS = range(4)
 # indices into the scalar block
 S_ETA, S_OMEGA, S_THETA, S_TAU, S_SIGMA, S_WPEND, S_ETASUM, S_K, S_INV1PT, S_ACCEPT, S_ETABAR, S_DEN = range(12)
 
@@ -68,6 +69,7 @@ SIGNATURES = {
     "pdlp_adaptive_update": (_I, [_H]),
     "pdlp_iterate": (_I, [_H, _I, _I]),
     "pdlp_set_exchange_chunks": (_I, [_H, _I]),
+    "pdlp_set_option": (_I, [_H, _I, _I64]),
     "pdlp_exchange_plan": (_I, [_H, _I, C.POINTER(C.c_int32), C.POINTER(_I64)]),
     "pdlp_half_chunk": (_I, [_H, _I, _I]),
     "pdlp_comm_load": (_I, [C.c_char_p]),
@@ -94,6 +96,8 @@ SIGNATURES = {
     "pdlp_infeas_finish": (_I, [_H, _D, C.POINTER(C.c_int32), C.POINTER(_D)]),
     "pdlp_mv_steps": (_I, [_H, _I, _I, _D, _D, _D, _P, _P, _P]),
     "pdlp_mv_gap": (_I, [_H, _I, _P, _P, _P, C.POINTER(_D)]),
+    "pdlp_mv_product": (_I, [_H, _I, _P, _P]),
+    "pdlp_mv_combine": (_I, [_I, _I64, _I, _P, _P, _I, _P, _P]),
     "pdlp_spmv": (_I, [_H, _I, _P, _P]),
     "pdlp_power_iteration": (_I, [_H, _P, _I, _P, _P, C.POINTER(_D)]),
     "pdlp_probe_stream_read": (_I, [_P, _I64, _I, _P, C.POINTER(_D)]),
@@ -103,6 +107,7 @@ SIGNATURES = {
     "pdlp_vec_muldiv": (_I, [_I, _I64, _P, _P, _I, _P]),
     "pdlp_vec_project_lambda": (_I, [_I, _I64, _P, _P, _P, _P, _P]),
     "pdlp_vec_max_dev_from_one": (_I, [_I, _I64, _P, _P, C.POINTER(_D), _P]),
+    "pdlp_vec_sqdist": (_I, [_I, _I64, _P, _P, _P, C.POINTER(_D), _P]),
 }
 
 _lib = None

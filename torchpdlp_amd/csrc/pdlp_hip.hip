@@ -269,7 +269,9 @@ struct pdlp_solver {
     bool kx_valid, cand_valid[2];
     char* ktyb[2];                // K'y of the candidates, kept by their KKT passes: [0] current, [1] averaged iterate
     int kty_cur;                  // which of the two belongs to the CURRENT iterate after a restart (-1: see cand_valid[0])
-    bool no_kty_reuse;            // PDLP_NO_KTY_REUSE: timing experiments
+    bool no_kty_reuse;            // PDLP_OPT_KTY_REUSE = 0: timing experiments
+    int split_local, split_other; // PDLP_OPT_SPLIT_SLOTS: panel groups of a split product chosen by the caller (0: the library's rule)
+    bool side_ok;                 // the library's own streams and events exist (graph replay, split products)
     // running products: K x (kxb[0]) is carried along by every dual half-step and both products are summed with the
     // average's weights (kx_sum, kty_sum), so a restart check evaluates K x_cur, K x_avg and K'y_avg WITHOUT products:
     // one product (K'y_cur, kept for the next primal half-step) instead of four per check
@@ -279,7 +281,7 @@ struct pdlp_solver {
     bool sums_broken;             // a term was lost (flush before the K'y of the current iterate existed): no running average
     bool avg_products;            // kxb[2] / ktyb[1] hold K x_avg / K'y_avg computed from the sums
     bool cur_kx_cached;           // the KKT pass of the current iterate took K x from the cache (nothing to swap on restart)
-    bool no_running;              // PDLP_RUNNING_KKT=0: every KKT pass multiplies (round-1 behaviour)
+    bool no_running;              // PDLP_OPT_RUNNING_KKT = 0: every KKT pass multiplies (round-1 behaviour)
     double *partA, *partB, *red, *sc;
     void* rowsum;                 // row sums of the tiled kernel on their way to the epilogue: [groups][rs_stride]
     int64_t rs_stride;            // rows + one row block
@@ -639,9 +641,9 @@ int configure_split(pdlp_handle h, bool transpose)
         if (a + b > h->rs_groups) b = h->rs_groups - a;
         if (a < 1 || b < 1) return PDLP_OK;
         int S = a + b;
-        if (const char* ov = std::getenv("PDLP_SPLIT_SLOTS")) {           // experiments: "local,other"
-            int oa = 0, ob = 0;
-            if (std::sscanf(ov, "%d,%d", &oa, &ob) == 2 && oa >= 1 && ob >= 1 && oa + ob <= h->rs_groups) { a = oa; S = oa + ob; }
+        if (h->split_local >= 1 && h->split_other >= 1 && h->split_local + h->split_other <= h->rs_groups) {   // PDLP_OPT_SPLIT_SLOTS (tools)
+            a = h->split_local;
+            S = h->split_local + h->split_other;
         }
         g[0] = norm(a, nloc);
         g[1] = norm(S - a, nrem);
@@ -1031,6 +1033,23 @@ template <typename T, int NVP> int mv_gap_n(pdlp_handle h, const T* X, const T* 
     return PDLP_OK;
 }
 
+template <typename T, int NVP> int mv_product_n(pdlp_handle h, const T* X, T* Y)
+{
+    const int64_t m = h->p.m;
+    StoreMV<T> st{Y};
+    hipLaunchKernelGGL((k_csr_mv<T, NVP, StoreMV<T>>), dim3(mv_grid(m, NVP)), dim3(BLOCK), 0, h->stream, (int)m, h->p.K_rowptr,
+                       h->p.K_colidx, (const T*)h->p.K_val, X, st, (double*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return PDLP_OK;
+}
+
+template <typename T> int mv_product_t(pdlp_handle h, int nvp, const void* X, void* Y)
+{
+    if (nvp == 8) return mv_product_n<T, 8>(h, (const T*)X, (T*)Y);
+    if (nvp == 16) return mv_product_n<T, 16>(h, (const T*)X, (T*)Y);
+    return mv_product_n<T, 32>(h, (const T*)X, (T*)Y);
+}
+
 template <typename T> int mv_steps_t(pdlp_handle h, int nvp, int steps, double eta, double omega, double theta, void* X, void* Y, void* work)
 {
     if (nvp == 8) return mv_steps_n<T, 8>(h, steps, eta, omega, theta, (T*)X, (T*)Y, (T*)work);
@@ -1139,7 +1158,7 @@ int read_last_rowptr(const int64_t* rp, int64_t rows, int64_t* nnz, hipStream_t 
 // ================================================================================================
 extern "C" {
 
-int pdlp_abi_version(void) { return 15; }  // 15: 64-bit row pointers, row-block bases of the tiles and schedule offsets (more than 2^31 non-zeros per handle); 14: pdlp_probe_stream_read; 13: chunked exchange (pdlp_set_exchange_chunks, pdlp_exchange_plan, pdlp_half_chunk); 12: count words of a tile laid out for coalesced loads; 11: pdlp_comm_load; 10: pdlp_set_anchors; 9: pdlp_attach_sorted; 8: running products, pdlp_flush_average(h, adaptive); 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
+int pdlp_abi_version(void) { return 16; }  // 16: pdlp_set_option (the library reads no environment variables), pdlp_mv_product, pdlp_mv_combine, pdlp_vec_sqdist; 15: 64-bit row pointers, row-block bases of the tiles and schedule offsets (more than 2^31 non-zeros per handle); 14: pdlp_probe_stream_read; 13: chunked exchange (pdlp_set_exchange_chunks, pdlp_exchange_plan, pdlp_half_chunk); 12: count words of a tile laid out for coalesced loads; 11: pdlp_comm_load; 10: pdlp_set_anchors; 9: pdlp_attach_sorted; 8: running products, pdlp_flush_average(h, adaptive); 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
 
 const char* pdlp_strerror(int code)
 {
@@ -1219,9 +1238,10 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
         h->sKT.ptab = (int32_t*)(w + offs[41]); h->sKT.ptab_cap = (p->m >> 4) + 8;
     }
     h->since_reset = 0; h->kty_tail_done = false; h->avg_products = false; h->sums_broken = false; h->cur_kx_cached = false;
-    h->no_running = std::getenv("PDLP_RUNNING_KKT") != nullptr && std::getenv("PDLP_RUNNING_KKT")[0] == '0';
+    h->no_running = false;
     h->kty_cur = -1;
-    h->no_kty_reuse = std::getenv("PDLP_NO_KTY_REUSE") != nullptr;
+    h->no_kty_reuse = false;
+    h->split_local = h->split_other = 0;
     h->rs_stride = (nl > ml ? nl : ml) + (int64_t)TNT * TRPT_MAX_ANY;
     h->rs_groups = (int)rowsum_groups(nl > ml ? nl : ml);
     h->part_blocks = MAX_GRID + LONG_GRID + (nl > ml ? nl : ml) / TNT + 2;
@@ -1240,7 +1260,8 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
         h->gstream = nullptr;
         (void)hipGetLastError();
     }
-    h->graph_ok = side && std::getenv("PDLP_GRAPH") != nullptr;
+    h->graph_ok = false;              // pdlp_set_option(PDLP_OPT_GRAPH) turns the replay on
+    h->side_ok = side;
     h->use_split = false;
 
     h->sK.rplo = (uint32_t*)(w + offs[42]); h->sKT.rplo = (uint32_t*)(w + offs[43]);
@@ -1465,6 +1486,31 @@ int pdlp_split_info(pdlp_handle h, int transpose, int32_t out[4])
     const Schedule& s = transpose ? h->sKT : h->sK;
     out[0] = s.loc_pa; out[1] = s.loc_pb; out[2] = s.slotsA; out[3] = s.slotsB;
     return PDLP_OK;
+}
+
+int pdlp_set_option(pdlp_handle h, int option, int64_t value)
+{
+    if (!h) return PDLP_ERR_INVALID;
+    if (h->sK.pending || h->sKT.pending) return PDLP_ERR_STATE;       // not in the middle of a split product
+    switch (option) {
+        case PDLP_OPT_RUNNING_KKT: h->no_running = value == 0; return PDLP_OK;
+        case PDLP_OPT_KTY_REUSE: h->no_kty_reuse = value == 0; return PDLP_OK;
+        case PDLP_OPT_GRAPH:
+            drop_graphs(h);
+            h->graph_ok = value != 0 && h->side_ok && !h->comm;
+            return (value != 0 && !h->graph_ok) ? PDLP_ERR_STATE : PDLP_OK;
+        case PDLP_OPT_SPLIT_SLOTS: {
+            const int a = (int)(value & 0xffff), b = (int)((value >> 16) & 0xffff);
+            if (value != 0 && (a < 1 || b < 1 || a + b > h->rs_groups)) return PDLP_ERR_INVALID;
+            h->split_local = a;
+            h->split_other = b;
+            drop_graphs(h);
+            int rc = configure_split(h, false);
+            if (rc == PDLP_OK) rc = configure_split(h, true);
+            return rc;
+        }
+        default: return PDLP_ERR_INVALID;
+    }
 }
 
 int pdlp_set_exchange_chunks(pdlp_handle h, int chunks)
@@ -1938,6 +1984,26 @@ int pdlp_mv_gap(pdlp_handle h, int nvp, const void* X, const void* Y, void* work
     return DISPATCH(h, mv_gap_t, h, nvp, X, Y, work, gaps);
 }
 
+int pdlp_mv_product(pdlp_handle h, int nvp, const void* X, void* Y)
+{
+    if (!h || !X || !Y || (nvp != 8 && nvp != 16 && nvp != 32)) return PDLP_ERR_INVALID;
+    if (h->nl != h->p.n || h->ml != h->p.m || h->mixed) return PDLP_ERR_STATE;
+    return DISPATCH(h, mv_product_t, h, nvp, X, Y);
+}
+
+int pdlp_mv_combine(int dtype, int64_t rows, int j, const void* V, const void* W, int nw, void* OUT, void* stream)
+{
+    if (rows < 0 || j < 1 || j > 32 || nw < 1 || nw > 32 || !V || !W || !OUT || (dtype != PDLP_F32 && dtype != PDLP_F64)) return PDLP_ERR_INVALID;
+    if (rows == 0) return PDLP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PDLP_F32)
+        hipLaunchKernelGGL(k_mv_combine<float>, dim3(grid_for(rows * nw)), dim3(BLOCK), 0, s, rows, j, (const float*)V, (const float*)W, nw, (float*)OUT);
+    else
+        hipLaunchKernelGGL(k_mv_combine<double>, dim3(grid_for(rows * nw)), dim3(BLOCK), 0, s, rows, j, (const double*)V, (const double*)W, nw, (double*)OUT);
+    HIP_TRY(hipGetLastError());
+    return PDLP_OK;
+}
+
 int pdlp_spmv(pdlp_handle h, int transpose, const void* in_full, void* out_local)
 {
     if (!h || !in_full || !out_local) return PDLP_ERR_INVALID;
@@ -2097,6 +2163,27 @@ int pdlp_vec_max_dev_from_one(int dtype, int64_t len, const void* v, void* work8
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMemcpyAsync(out, work8, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return PDLP_OK;
+}
+
+int pdlp_vec_sqdist(int dtype, int64_t len, const void* a, const void* b, void* work, double* out, void* stream)
+{
+    if (len < 0 || !work || !out || (len > 0 && (!a || !b)) || (dtype != PDLP_F32 && dtype != PDLP_F64)) return PDLP_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    *out = 0.0;
+    if (len == 0) return PDLP_OK;
+    // partial sums of <= 256 workgroups at work[b * NACC], added in fixed order by one workgroup into work[256 * NACC]
+    const int64_t want = (len + BLOCK - 1) / BLOCK;
+    const int grid = (int)(want < 256 ? want : 256);
+    double* part = (double*)work;
+    if (dtype == PDLP_F32)
+        hipLaunchKernelGGL(k_sqdiff<float>, dim3(grid), dim3(BLOCK), 0, s, len, (const float*)a, (const float*)b, part);
+    else
+        hipLaunchKernelGGL(k_sqdiff<double>, dim3(grid), dim3(BLOCK), 0, s, len, (const double*)a, (const double*)b, part);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, s, (const double*)part, grid, 1, part + 256 * NACC, 0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, part + 256 * NACC, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return PDLP_OK;
 }

@@ -145,6 +145,13 @@ class PdlpEngine:
                                      nbytes.value), "pdlp_create")
         self._views = {}
         self._want_tiles = bool(tiles)
+        # test / tool knobs of the handle (the library reads no environment: pdlp_set_option)
+        if os.environ.get("PDLP_RUNNING_KKT", "1")[:1] == "0":
+            self.set_option(N.OPT_RUNNING_KKT, 0)
+        if os.environ.get("PDLP_NO_KTY_REUSE") is not None:
+            self.set_option(N.OPT_KTY_REUSE, 0)
+        if os.environ.get("PDLP_GRAPH") is not None and self.comm is None:
+            self.set_option(N.OPT_GRAPH, 1)
         self.exact = None
         if exact is not None:          # the true float64 matrix, CSR kernels only: two products per restart
             self.exact = PdlpEngine(m, n, m_ineq, exact[0], exact[1], c, q, l, u, rows=rows, cols=cols, comm=comm, tiles=False)
@@ -164,6 +171,10 @@ class PdlpEngine:
         self.lib_comm, self.lib_comm_log = False, []
         if self.comm is not None and self.comm.backend == "nccl" and tiles and os.environ.get("PDLP_LIB_COMM", "0") == "1":
             self.enable_library_comm()
+
+    def set_option(self, option: int, value: int):
+        """``pdlp_set_option``: the handle's test / tool switches (``N.OPT_*``)"""
+        N.check(self.lib.pdlp_set_option(self.h, int(option), int(value)), "pdlp_set_option")
 
     # ---- panel-tiled matrix copies (fast path for wide gathered vectors) -------------------------------
     def tile_limits(self) -> dict:
@@ -715,6 +726,26 @@ class PdlpEngine:
         out = (C.c_double * j)()
         N.check(self.lib.pdlp_mv_gap(self.h, j, X.data_ptr(), Y.data_ptr(), work.data_ptr(), out), "pdlp_mv_gap")
         return list(out)
+
+    def mv_product(self, X: torch.Tensor) -> torch.Tensor:
+        """K X for a population X (n x j, j in MV_WIDTHS) in one pass over K -- ``pts_y = K @ pts`` (spectral_casting.py:100)"""
+        Y = torch.empty(self.m, int(X.shape[1]), dtype=self.dtype, device=self.device)
+        j = self._mv_check(X, Y)
+        N.check(self.lib.pdlp_mv_product(self.h, j, X.data_ptr(), Y.data_ptr()), "pdlp_mv_product")
+        return Y
+
+    def mv_combine(self, V: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
+        """V @ W for a population V (rows x j, j <= 32) and weights W (j x nw, nw <= 32) -- the convex combinations of the breeding
+        rounds (spectral_casting.py:133-141)"""
+        V, W = V.contiguous(), W.to(device=self.device, dtype=self.dtype).contiguous()
+        rows, j = V.shape
+        nw = int(W.shape[1])
+        if W.shape[0] != j or not (1 <= j <= 32 and 1 <= nw <= 32) or V.dtype != self.dtype or V.device != self.device:
+            raise ValueError(f"mv_combine: {tuple(V.shape)} @ {tuple(W.shape)}")
+        out = torch.empty(rows, nw, dtype=self.dtype, device=self.device)
+        N.check(self.lib.pdlp_mv_combine(N.PDLP_F32 if self.dtype == torch.float32 else N.PDLP_F64, rows, j, V.data_ptr(), W.data_ptr(), nw,
+                                         out.data_ptr(), self.stream.cuda_stream), "pdlp_mv_combine")
+        return out
 
     def _mv_check(self, X, Y) -> int:
         if self.comm is not None:

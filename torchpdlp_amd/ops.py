@@ -9,6 +9,7 @@ which keep all state on the GPU between iterations.
 """
 from __future__ import annotations
 
+import ctypes as C
 import time
 import weakref
 
@@ -130,10 +131,22 @@ def KKT_error(x, y, c, q, K, m_ineq, omega, is_neg_inf=None, is_pos_inf=None, l_
 def primal_weight_update(x_prev, x, y_prev, y, omega, smooth_theta):
     """primal_weight_update (enhancements.py:73-78); the two norms come from the device."""
     dev = _device_of(x, y)
-    dx2 = float(((as_vec(x_prev, device=dev) - as_vec(x, device=dev)).double() ** 2).sum())
-    dy2 = float(((as_vec(y_prev, device=dev) - as_vec(y, device=dev)).double() ** 2).sum())
-    t = np.float32 if as_vec(x).dtype == torch.float32 else np.float64
-    return _scalar_like(omega, float(primal_weight_from_distances(dx2, dy2, float(omega), smooth_theta, t)), as_vec(x).dtype)
+    lib = N.load()
+    dt = as_vec(x).dtype if as_vec(x).dtype in (torch.float32, torch.float64) else torch.float32
+    work = torch.empty(1040, dtype=torch.float64, device=dev)
+
+    def sqdist(a, b):                      # k_sqdiff + k_finalize: the kernels of pdlp_restart_distance_local
+        a, b = as_vec(a, device=dev, dtype=dt), as_vec(b, device=dev, dtype=dt)
+        if a.numel() != b.numel():
+            raise ValueError("primal_weight_update: vectors of different lengths")
+        out = C.c_double(0.0)
+        N.check(lib.pdlp_vec_sqdist(N.PDLP_F32 if dt == torch.float32 else N.PDLP_F64, a.numel(), a.data_ptr(), b.data_ptr(),
+                                    work.data_ptr(), C.byref(out), torch.cuda.current_stream(dev).cuda_stream), "pdlp_vec_sqdist")
+        return out.value
+
+    dx2, dy2 = sqdist(x_prev, x), sqdist(y_prev, y)
+    t = np.float32 if dt == torch.float32 else np.float64
+    return _scalar_like(omega, float(primal_weight_from_distances(dx2, dy2, float(omega), smooth_theta, t)), dt)
 
 
 def project_lambda_box(grad, is_neg_inf, is_pos_inf):

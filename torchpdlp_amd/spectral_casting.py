@@ -50,8 +50,12 @@ def fishnet(eng: PdlpEngine, pts: torch.Tensor, s: int = 2, k: int = 32, eta: Op
     dev, dt = eng.device, eng.dtype
     pts = pts.to(device=dev, dtype=dt)                                # the population lives on the device (n x j, m x j)
     j = pts.shape[1]
-    # pts_y = K @ pts (:100)
-    ys = torch.stack([eng.spmv(pts[:, p].contiguous(), False) for p in range(j)], dim=1)
+    # pts_y = K @ pts (:100): one pass over K for all points where the population kernels apply, else point by point
+    if multi_vector and eng.comm is None and not eng.mixed and j in eng.MV_WIDTHS:
+        pts = pts.contiguous()
+        ys = eng.mv_product(pts)
+    else:
+        ys = torch.stack([eng.spmv(pts[:, p].contiguous(), False) for p in range(j)], dim=1)
     if eta is None:                                                   # init_PDHG_vars :161-189
         if b0 is None:
             b0 = torch.randn(eng.n, generator=generator, dtype=torch.float32, device="cpu" if generator is not None else dev)
@@ -81,13 +85,20 @@ def fishnet(eng: PdlpEngine, pts: torch.Tensor, s: int = 2, k: int = 32, eta: Op
         new_j = keep
         if i % 2 == 1 and new_j > 1:                                  # breed on odd rounds (:117-152)
             mid, mid_y = pts.mean(dim=1, keepdim=True), ys.mean(dim=1, keepdim=True)
-            new_x, new_y = [], []
+            ws = []
             for _ in range(old_j - new_j - 1):
                 w = torch.rand(new_j, generator=generator, device="cpu" if generator is not None else dev)
-                w = (w / w.sum()).to(device=dev, dtype=dt)
-                new_x.append(pts @ w.view(-1, 1))
-                new_y.append(ys @ w.view(-1, 1))
-            if new_x:
+                ws.append((w / w.sum()).to(device=dev, dtype=dt))
+            if ws:                                                    # the convex combinations: pts @ W, ys @ W (k_mv_combine)
+                new_x, new_y = [], []
+                for w0 in range(0, len(ws), 32):
+                    W = torch.stack(ws[w0:w0 + 32], dim=1)
+                    if new_j <= 32:
+                        new_x.append(eng.mv_combine(pts, W))
+                        new_y.append(eng.mv_combine(ys, W))
+                    else:                                             # (populations beyond the kernels' 32 columns)
+                        new_x.append(pts @ W)
+                        new_y.append(ys @ W)
                 pts = torch.cat([pts] + new_x + [mid], dim=1)
                 ys = torch.cat([ys] + new_y + [mid_y], dim=1)
         j = pts.shape[1]
