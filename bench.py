@@ -39,6 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+INFINITY_CACHE_BYTES = 256 << 20   # MI355X_MICROARCH.md: 256 MB of memory-side cache in front of HBM
 
 
 def spawn_ranks(gpus: int, argv, script: str = None, env: dict = None, launch_timeout: float = None, grace: float = None) -> int:
@@ -124,9 +125,19 @@ def spawn_ranks(gpus: int, argv, script: str = None, env: dict = None, launch_ti
         if ln not in result:
             print(ln, file=sys.stderr)
     if result:
+        line = result[-1]
         if rc != 0 or why is not None:
+            # a salvaged line is still the measurement (exit code 0: the driver must not lose it), but it says so itself
             print("bench.py: relaying the result line that was measured before the failure", file=sys.stderr)
-        print(result[-1], flush=True)
+            reason = why if why is not None else f"a rank exited with code {rc} after the result line"
+            try:
+                obj = json.loads(line)
+                obj["degraded"] = True
+                obj["degraded_reason"] = (obj.get("degraded_reason", "") + "; " if obj.get("degraded_reason") else "") + reason
+                line = json.dumps(obj)
+            except Exception:
+                pass
+        print(line, flush=True)
         return 0
     if rc != 0:
         return rc
@@ -159,7 +170,8 @@ def parse(argv=None):
                    help="after the timed region: a full restarted solve of the same LP to this relative KKT tolerance (the second half "
                         "of BASELINE's metric, reported as time_to_tol; N=1 only; 0 = skip)")
     p.add_argument("--solve-limit", type=float, default=120.0, help="time limit of that solve, seconds")
-    p.add_argument("--cpu-sample-rows", type=int, default=500_000)
+    p.add_argument("--cpu-sample-rows", type=int, default=4_000_000,
+                   help="most rows (= columns) of the CPU baseline's sample; the host's free memory may lower it")
     p.add_argument("--kernel-reps", type=int, default=20)
     p.add_argument("--check-periods", type=int, default=5, help="restart periods the cost of one check is averaged over (after the timed region)")
     return p.parse_args(argv)
@@ -197,8 +209,8 @@ def time_half_steps(eng, adaptive, reps):
     return (sum(e0.elapsed_time(e1) for e0, e1, _ in evs) / reps, sum(e1.elapsed_time(e2) for _, e1, e2 in evs) / reps)
 
 
-def host_cores() -> int:
-    """CPU cores this process may really use: cgroup quota, then affinity, then the machine's count."""
+def available_cores() -> int:
+    """CPU cores this process may really use: its affinity mask, cut by a cgroup quota if there is one"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -206,7 +218,33 @@ def host_cores() -> int:
             n = min(n, max(1, int(int(quota) / int(period))))
     except Exception:
         pass
-    return max(1, min(n, int(os.environ.get("PDLP_CPU_THREADS", "16"))))   # a 1-GPU box shares its host: 16 cores
+    return max(1, n)
+
+
+def host_cores() -> int:
+    """threads of the CPU baseline: every core available to this process (SURVEY 8d: "all physical cores, count stated");
+    PDLP_CPU_THREADS caps it"""
+    cap = os.environ.get("PDLP_CPU_THREADS")
+    return max(1, min(available_cores(), int(cap))) if cap else available_cores()
+
+
+def host_memory_bytes() -> int:
+    """memory the CPU baseline's sample may plan with: MemAvailable, cut by a cgroup limit if there is one"""
+    avail = 16 << 30
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+    except Exception:
+        pass
+    try:
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        if lim != "max":
+            used = int(open("/sys/fs/cgroup/memory.current").read())
+            avail = min(avail, max(0, int(lim) - used))
+    except Exception:
+        pass
+    return avail
 
 
 def cpu_baseline(args, sv_dtype):
@@ -215,42 +253,63 @@ def cpu_baseline(args, sv_dtype):
     non-zeros per row; the rate is scaled by non-zero count to the full workload (SpMV dominated)."""
     from oracle import oracle as orc       # checker/baseline only -- never on the product path
     import numpy as np
-    rows = min(args.cpu_sample_rows, args.n)
+    # the largest sample the host's memory allows (both CSR copies as numpy arrays + the torch tensors they are copied from: about
+    # 40 bytes per non-zero while the oracle is being set up), at most --cpu-sample-rows (default 4M rows: 3.2 GB per copy at 100 per
+    # row -- far beyond the caches of any host, and a bench run still ends within minutes)
+    mem_rows = int(0.5 * host_memory_bytes() / (40.0 * args.nnz_per_row))
+    rows = max(1000, min(args.cpu_sample_rows, args.n, mem_rows))
     lp = tp.gen_lp(rows, rows, args.nnz_per_row, seed=0, device="cuda", dtype=sv_dtype)
     K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
     h = lambda t: t.cpu().numpy()
     o = orc.OracleLP(lp.m, lp.n, lp.m_ineq, h(K.rowptr), h(K.colidx), h(K.val), h(lp.c), h(lp.q), h(lp.l), h(lp.u),
                      dtype=np.float32 if sv_dtype == torch.float32 else np.float64,
                      trans=(h(K.t_rowptr), h(K.t_colidx), h(K.t_val)))
-    cores = orc.set_threads(host_cores())
-    x, y = np.zeros(lp.n, o.dtype), np.zeros(lp.m, o.dtype)
-    eta, om = o.dtype.type(0.01), o.dtype.type(1.0)
     adaptive = args.mode == "adaptive"
-
-    def one(k, x, y, eta):
-        if adaptive:
-            x, y, _, eta, _ = o.step_adaptive(x, y, eta, om, 1.0, k)
-        else:
-            x, y = o.step_fixed(x, y, eta, om, 1.0)
-        return x, y, eta
-    x, y, eta = one(1, x, y, eta)
-    t0, iters = time.time(), 0
-    while iters < 3 or (time.time() - t0 < 10.0 and iters < 200):
-        x, y, eta = one(iters + 2, x, y, eta)
-        iters += 1
-    step_s = (time.time() - t0) / iters
-    t1 = time.time()
-    o.kkt(x, y, om)
-    kkt_s = time.time() - t1
-    per_iter = step_s + 3.0 * kkt_s / 40.0            # the reference's restart cadence
     scale = (lp.nnz / float(args.nnz_per_row * (args.m or args.n)))
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    out = dict(value=round(scale / per_iter, 4), unit="iterations/s", cores=cores, kind="port",
+    avail = available_cores()
+
+    def measure(threads, budget_s):
+        """>= 3 iterations (and up to `budget_s` seconds) of the oracle with `threads` OpenMP threads + one KKT pass"""
+        cores = orc.set_threads(threads)
+        x, y = np.zeros(lp.n, o.dtype), np.zeros(lp.m, o.dtype)
+        eta, om = o.dtype.type(0.01), o.dtype.type(1.0)
+
+        def one(k, x, y, eta):
+            if adaptive:
+                x, y, _, eta, _ = o.step_adaptive(x, y, eta, om, 1.0, k)
+            else:
+                x, y = o.step_fixed(x, y, eta, om, 1.0)
+            return x, y, eta
+        x, y, eta = one(1, x, y, eta)
+        t0, iters = time.time(), 0
+        while iters < 3 or (time.time() - t0 < budget_s and iters < 200):
+            x, y, eta = one(iters + 2, x, y, eta)
+            iters += 1
+        step_s = (time.time() - t0) / iters
+        o.kkt(x, y, om)
+        t1 = time.time()
+        o.kkt(x, y, om)
+        kkt_s = time.time() - t1
+        per_iter = step_s + 3.0 * kkt_s / 40.0            # the reference's restart cadence
+        return dict(value=round(scale / per_iter, 4), cores=cores, iterations=iters, step_ms=round(step_s * 1e3, 2), kkt_ms=round(kkt_s * 1e3, 2))
+    orc.set_threads(host_cores())
+    if host_cores() > 16:
+        o.spread()                           # (NUMA: pages of the matrix arrays go to the threads that stream them)
+    top = measure(host_cores(), 10.0)
+    cores = top["cores"]
+    out = dict(value=top["value"], unit="iterations/s", cores=cores, kind="port",
                machine_cores=os.cpu_count(), cores_available_to_this_process=avail,
-               cores_cap=int(os.environ.get("PDLP_CPU_THREADS", "16")),
-               sample=f"oracle (C, OpenMP, CSR + pre-transposed CSR) on gen_lp({rows}x{rows}, {args.nnz_per_row} nnz/row, seed 0): "
-                      f"{iters} {args.mode} iterations at {step_s * 1e3:.1f} ms + KKT pass {kkt_s * 1e3:.1f} ms x3/40; "
+               sample=f"oracle (C, OpenMP, CSR + pre-transposed CSR) on gen_lp({rows}x{rows}, {args.nnz_per_row} nnz/row, seed 0), {cores} threads: "
+                      f"{top['iterations']} {args.mode} iterations at {top['step_ms']:.1f} ms + KKT pass {top['kkt_ms']:.1f} ms x3/40; "
                       f"rate scaled by nnz ratio {scale:.4g} to the full workload")
+    if cores > 16:     # the figure of rounds 1-4 (a 1-GPU box's CPU share) beside it
+        try:
+            sub = measure(16, 6.0)
+            out["sixteen_cores"] = dict(value=sub["value"], unit="iterations/s", cores=sub["cores"],
+                                        sample=f"same sample, 16 threads: {sub['iterations']} iterations at {sub['step_ms']:.1f} ms + KKT pass {sub['kkt_ms']:.1f} ms x3/40")
+        except Exception as ex:
+            out["sixteen_cores"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
+        orc.set_threads(cores)
     # flavour (i) of SURVEY 8d: what the reference itself does on a CPU -- eager torch ops on a sparse-COO K with K.T @ y
     try:
         from oracle.torch_coo import TorchCooLP
@@ -335,6 +394,33 @@ def measure_roofline(args, eng, dt, adaptive, world):
         if ceiling:
             roofline["measured_read_ceiling"] = {"value": ceiling["GBs"], "unit": "GB/s", "frac": round(achieved / ceiling["GBs"], 4),
                                                  "source": ceiling["source"] + f" (recorded; live probe failed: {type(ex).__name__})"}
+    # The right roof for an LP that lives in the Infinity Cache (256 MB): a CSR product whose gathers share no cache lines is bound by
+    # the rate at which the vector memory path serves scattered 4-byte gathers, not by HBM.  Probe that rate in THIS run -- the CSR
+    # kernel's launch shape, a table as long as the gathered vector, as many items as the matrix has -- and report both fractions.
+    try:
+        working_set = (nnz_k + nnz_kt) * (sm + si) + 12 * (eng.n + eng.m) * sv
+        dom_t = 1 if ms_primal >= ms_dual else 0
+        if working_set <= INFINITY_CACHE_BYTES and eng.tiles[dom_t] is None and eng.dtype == torch.float32:
+            import ctypes as C
+            entries = eng.m if dom_t else eng.n                      # K'y gathers y, K xbar gathers xbar
+            items = max(nnz_kt if dom_t else nnz_k, 1 << 22)
+            scratch = torch.empty(4 * entries + (1 << 20) + 8 * items + 8 * 4096, dtype=torch.uint8, device=eng.device)
+            off = (-scratch.data_ptr()) % 256
+            g = C.c_double(0)
+            N.check(eng.lib.pdlp_probe_gather(scratch.data_ptr() + off, scratch.numel() - off, entries, 10, eng.stream.cuda_stream, C.byref(g)),
+                    "pdlp_probe_gather")
+            del scratch
+            rate = (nnz_kt if dom_t else nnz_k) / (kms * 1e-3) / 1e9
+            roofline["bound"] = "gather"
+            roofline["gather_ceiling"] = {"value": round(g.value, 1), "unit": "G items/s",
+                                          "source": f"this run: pdlp_probe_gather, {items} items of 8 bytes + one uniform random 4-byte gather each over "
+                                                    f"{entries} floats, k_csr_fused's launch shape, 10 launches"}
+            roofline["achieved_items"] = {"value": round(rate, 1), "unit": "G items/s"}
+            roofline["frac_of_gather_ceiling"] = round(rate / g.value, 4)
+            roofline["note"] = ("working set %.0f MB <= the 256 MB Infinity Cache: the kernel is bound by scattered gathers (one 128-byte line per "
+                                "4-byte gather), `frac` (of the HBM peak) is kept for comparison only" % (working_set / 1e6))
+    except Exception as ex:
+        roofline["gather_ceiling"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
     return roofline
 
 
@@ -391,6 +477,10 @@ class Deadman:
             if not ev.wait(seconds):
                 try:
                     line = line_fn()
+                    obj = json.loads(line)
+                    obj["degraded"] = True
+                    obj["degraded_reason"] = f"{why}: no progress for {seconds:.0f} s, rank {rank} left with the line already measured"
+                    line = json.dumps(obj)
                 except Exception:
                     line = None
                 if rank == 0 and line:
@@ -407,15 +497,17 @@ class Deadman:
 
 
 def library_phase(out: dict, exchange: dict, eng, steps: int, timed_region, norm_elapsed: float, rank: int, limit: float = 90.0,
-                  slack: float = 120.0):
+                  slack: float = 120.0, first_region_s: float = 0.0):
     """N > 1 under RCCL, AFTER the headline was measured on the torch.distributed loop: try the library's own communicator (one C call
     per restart period), cross-checked bit for bit against that loop, and repeat the timed region on it.  Whatever happens in here --
     a hang inside ncclCommInitRank included -- the line already measured is what gets printed.  Every decision uses numbers that are
     maxima over the ranks, so all ranks take the same branch."""
+    # the deadline covers the communicator's set-up (2 x limit) AND a second timed region: three times the wall time of the first
+    deadline = 2 * limit + slack + 3.0 * float(first_region_s)
     snapshot = json.dumps(dict(out, config=dict(out["config"], exchange=dict(
-        exchange, path=f"torch.distributed loop (library path abandoned by the watchdog after {2 * limit + slack:.0f} s)"))))
+        exchange, path=f"torch.distributed loop (library path abandoned by the watchdog after {deadline:.0f} s)"))))
     deadman = Deadman(rank)
-    deadman.arm(2 * limit + slack, lambda: snapshot, "the library communicator phase hung")
+    deadman.arm(deadline, lambda: snapshot, "the library communicator phase hung")
     try:
         on = eng.enable_library_comm(timeout=limit, cross_check=True)
         exchange["log"] = list(getattr(eng, "lib_comm_log", []))
@@ -583,7 +675,9 @@ def main(argv=None):
     # N > 1: the headline is measured on the torch.distributed loop FIRST; the library's own communicator (first contact with a
     # second RCCL communicator) is tried only afterwards, under a watchdog that prints the line already measured if it hangs
     setup_s = time.time() - t_setup
+    t_region = time.time()
     reg = timed_region()
+    first_region_s = time.time() - t_region
     period, extra, elapsed, norm_elapsed = reg["period"], reg["extra"], reg["elapsed"], reg["norm_elapsed"]
     checks_in, restarts_in, checks_m, restarts_m, check_s = reg["checks_in"], reg["restarts_in"], reg["checks_m"], reg["restarts_m"], reg["check_s"]
 
@@ -614,21 +708,27 @@ def main(argv=None):
         "setup_s": round(setup_s, 1),
     }
     out["config"].update(notes)
+    deadman = Deadman(rank)
     if exchange is not None:
+        exchange["env"] = {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "RCCL_MSCCL_ENABLE", "HSA_FORCE_FINE_GRAIN_PCIE")}
         out["config"]["exchange"] = exchange
+        # the headline is measured: from here on every collective runs under a watchdog that prints it (a rank that raises before a
+        # collective leaves its peers blocked inside it, and the try/except below would swallow the only trace)
+        snap0 = json.dumps(out)
+        deadman.arm(300.0 + 3.0 * first_region_s, lambda: snap0, "the per-phase timing of the exchange hung")
         try:
             out["timing"]["phases"] = exchange_phases(eng, comm, roofline, norm_elapsed / args.steps * 1e3)
         except Exception as e:
             out["timing"]["phases"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        deadman.disarm()
         if args.lib_comm == "auto" and comm.backend == "nccl" and eng.xchunks > 1:
             # (a chunked exchange stays on torch.distributed's own collectives here: the library's form of it -- grouped broadcasts
             # on a second stream -- has only ever run against the test stand-in, and a first contact belongs outside a benchmark)
             exchange["path"] = "torch.distributed loop (chunked exchange: library driver not tried)"
         elif args.lib_comm == "auto" and comm.backend == "nccl":
             library_phase(out, exchange, eng, args.steps, timed_region, norm_elapsed, rank,
-                          limit=float(os.environ.get("PDLP_COMM_TIMEOUT", "90")))
+                          limit=float(os.environ.get("PDLP_COMM_TIMEOUT", "90")), first_region_s=first_region_s)
     # from here on (time to tolerance, teardown of the communicators) a hang must not cost the line either
-    deadman = Deadman(rank)
     if comm is not None:
         deadman.arm(args.solve_limit + 600.0, lambda: json.dumps(dict(out, time_to_tol={"error": "abandoned by the watchdog"})),
                     "the phases after the timed region hung")
@@ -645,6 +745,8 @@ def main(argv=None):
             rec = os.path.join(ROOT, "profiles", "time_to_tol.json")
             if os.path.exists(rec):
                 ttt["recorded"] = json.load(open(rec)).get(f"n{args.n}_k{args.nnz_per_row}", None)
+                if isinstance(ttt["recorded"], dict):      # separate builder-run solves (tools/time_to_tol.py), not timed by this run
+                    ttt["recorded"] = dict(ttt["recorded"], builder_run=True)
             out["time_to_tol"] = ttt
         except Exception as e:
             out["time_to_tol"] = {"error": f"{type(e).__name__}: {e}"[:200]}

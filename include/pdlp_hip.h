@@ -186,8 +186,9 @@ int pdlp_dual_half_begin(pdlp_handle h, int adaptive);
  * panel groups of the local panels, panel groups of the others}; all zero = the product is not split */
 int pdlp_split_info(pdlp_handle h, int transpose, int32_t out[4]);
 /* what pdlp_attach_tiles accepts for this handle: out = {most panel groups (the row-sum scratch has that many slots),
- * most row blocks (slots of per-workgroup partial sums), most rows per thread, most items per tile} */
-int pdlp_tile_limits(pdlp_handle h, int32_t out[4]);
+ * most row blocks (slots of per-workgroup partial sums), most rows per thread, most items per tile, threads per workgroup of the
+ * tiled kernel (a row block is that many times rpt rows), 0 (reserved)} */
+int pdlp_tile_limits(pdlp_handle h, int32_t out[6]);
 /* adaptive rule, part 1: reduce this rank's ||dx||^2, ||dy||^2, dy'K dx into PDLP_BUF_RED[0..2]
  * (all-reduce them across ranks before part 2) -- step.py:91-96 */
 int pdlp_adaptive_reduce(pdlp_handle h);
@@ -340,6 +341,13 @@ int pdlp_power_iteration(pdlp_handle h, const void* b0, int iters, void* work_n,
  * in flight per thread; one warm-up launch, then `reps` timed ones (HIP events on `stream`).  bench.py reports it beside the
  * nominal 8 TB/s as `roofline.measured_read_ceiling`. */
 int pdlp_probe_stream_read(const void* buf, int64_t bytes, int reps, void* stream, double* gb_per_s);
+/* The other roof (no counterpart in the reference either): G items/s of "8 bytes of item stream + ONE random 4-byte gather per item"
+ * over a zero table of `table_entries` floats, in the CSR kernel's launch shape (256-thread workgroups, blocks of 2048 items, all
+ * item loads of a block in one round, then all gathers).  A CSR product whose gathers share no cache lines (5 non-zeros per row
+ * over 1M columns) cannot run faster than this, whatever HBM could stream: bench.py reports it as `roofline.gather_ceiling` when
+ * the working set lives in the Infinity Cache.  scratch: 256-byte aligned, >= 4 * table_entries + 1 MiB + 8 bytes per item to be
+ * streamed (the library fills it: table, then uniform random columns and unit values). */
+int pdlp_probe_gather(void* scratch, int64_t scratch_bytes, int64_t table_entries, int reps, void* stream, double* gitems_per_s);
 
 /* ---- Ruiz equilibration on CSR (ruiz_precondition enhancements.py:4-71) ---------------------- */
 /* norm[i] = sqrt(max_p |val[p]|) over row i, replaced by 1 when < eps (:49-50 / :54-55) */

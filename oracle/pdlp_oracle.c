@@ -43,3 +43,20 @@ int orc_set_threads(int t)
     return 1;
 #endif
 }
+
+/* Baseline plumbing (no reference counterpart): copy `n` elements of `elem` bytes with the loops' own static schedule, so that on a
+ * NUMA host every page of a matrix array is first touched by the thread that will stream it (dst must be freshly allocated and
+ * untouched).  Without it all pages sit on the node of the thread that filled the arrays and a many-core baseline measures one
+ * memory controller. */
+void orc_spread_copy(void* dst, const void* src, int64_t n, int elem)
+{
+    const int64_t chunk = 1 << 16;                     /* elements per piece */
+    const int64_t pieces = (n + chunk - 1) / chunk;
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < pieces; ++p) {
+        const int64_t a = p * chunk, b = (a + chunk < n) ? a + chunk : n;
+        const char* s = (const char*)src + a * elem;
+        char* d = (char*)dst + a * elem;
+        for (int64_t i = 0; i < (b - a) * elem; ++i) d[i] = s[i];
+    }
+}

@@ -1753,3 +1753,4 @@ def test_column_sorted_row_blocks_match_csr_order(monkeypatch, precision):
         x, y = e.get_iterate(N.CUR)
         outs.append((x, y, e.kkt(N.CUR, 1.0)["kkt"]))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+

@@ -115,11 +115,13 @@ def main(argv=None) -> int:
             print(f"Solver uses {r.time:.4f} seconds.\nStatus: {r.status}")
             results.append({"File": name, "Objective": f"{r.objective:.6f}", "Iterations (k)": r.iterations, "Restarts (n)": r.restarts,
                             "KKT Passes (j)": r.kkt_passes, "Time (s)": f"{r.time:.4f}", "Status": r.status})      # main.py:142-150
-            bad = failed_ranks(False, name)
+            failed = False
         except Exception as e:          # the reference records the failure and goes on (main.py:152-162)
             print(f"Solver failed for {name}. Error: {e}")
             results.append(_fail_row(name, "Solver failed", e))
-            bad = failed_ranks(True, name)
+            failed = True
+        # (outside the try: a store error in the agreement itself must not add a second row for the instance)
+        bad = failed_ranks(failed, name)
         if bad != 0 and bad != world:
             # only some ranks failed (out of memory on one shard, ...), or the ranks could not agree in time: they are out of step and
             # the next instance would hang in its first collective.  Rank 0 saves what there is -- the rows of the instances solved so

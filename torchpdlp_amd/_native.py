@@ -101,6 +101,7 @@ SIGNATURES = {
     "pdlp_spmv": (_I, [_H, _I, _P, _P]),
     "pdlp_power_iteration": (_I, [_H, _P, _I, _P, _P, C.POINTER(_D)]),
     "pdlp_probe_stream_read": (_I, [_P, _I64, _I, _P, C.POINTER(_D)]),
+    "pdlp_probe_gather": (_I, [_P, _I64, _I64, _I, _P, C.POINTER(_D)]),
     "pdlp_csr_row_scale_factors": (_I, [_I, _I64, _P, _P, _D, _P, _P]),
     "pdlp_csr_div_rows": (_I, [_I, _I64, _P, _P, _P, _P]),
     "pdlp_csr_div_cols": (_I, [_I, _I64, _P, _P, _P, _P]),

@@ -1079,8 +1079,8 @@ int check_problem(const pdlp_problem* p)
 // cannot fill 2 x 256 CUs, i.e. below about 10.5M rows
 inline int64_t rowsum_groups(int64_t rows)
 {
-    if (rows <= (int64_t)TNT * 40 * 128) return 24;               // (small shards: room for the local panels and several chunks' groups)
-    return rows <= (int64_t)TNT * 40 * 512 ? 8 : 1;
+    if (rows <= (int64_t)512 * 40 * 128) return 24;               // (small shards: room for the local panels and several chunks' groups)
+    return rows <= (int64_t)512 * 40 * 512 ? 8 : 1;
 }
 
 struct Carve {
@@ -1158,7 +1158,7 @@ int read_last_rowptr(const int64_t* rp, int64_t rows, int64_t* nnz, hipStream_t 
 // ================================================================================================
 extern "C" {
 
-int pdlp_abi_version(void) { return 16; }  // 16: pdlp_set_option (the library reads no environment variables), pdlp_mv_product, pdlp_mv_combine, pdlp_vec_sqdist; 15: 64-bit row pointers, row-block bases of the tiles and schedule offsets (more than 2^31 non-zeros per handle); 14: pdlp_probe_stream_read; 13: chunked exchange (pdlp_set_exchange_chunks, pdlp_exchange_plan, pdlp_half_chunk); 12: count words of a tile laid out for coalesced loads; 11: pdlp_comm_load; 10: pdlp_set_anchors; 9: pdlp_attach_sorted; 8: running products, pdlp_flush_average(h, adaptive); 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
+int pdlp_abi_version(void) { return 16; }  // 16: pdlp_set_option (the library reads no environment variables), pdlp_mv_product, pdlp_mv_combine, pdlp_vec_sqdist, pdlp_probe_gather, pdlp_tile_limits reports the threads per workgroup; 15: 64-bit row pointers, row-block bases of the tiles and schedule offsets (more than 2^31 non-zeros per handle); 14: pdlp_probe_stream_read; 13: chunked exchange (pdlp_set_exchange_chunks, pdlp_exchange_plan, pdlp_half_chunk); 12: count words of a tile laid out for coalesced loads; 11: pdlp_comm_load; 10: pdlp_set_anchors; 9: pdlp_attach_sorted; 8: running products, pdlp_flush_average(h, adaptive); 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
 
 const char* pdlp_strerror(int code)
 {
@@ -1542,9 +1542,11 @@ int pdlp_half_chunk(pdlp_handle h, int transpose, int chunk)
     return DISPATCH(h, half_chunk_t, h, false, h->xbar, chunk);
 }
 
-int pdlp_tile_limits(pdlp_handle h, int32_t out[4])
+int pdlp_tile_limits(pdlp_handle h, int32_t out[6])
 {
     if (!h || !out) return PDLP_ERR_INVALID;
+    out[4] = TNT;
+    out[5] = 0;
     out[0] = h->rs_groups;
     out[1] = (int32_t)(h->part_blocks > INT32_MAX ? INT32_MAX : h->part_blocks);
     out[2] = h->p.dtype == PDLP_F64 ? TileCfg<double, double>::RPT_MAX : TileCfg<float, float>::RPT_MAX;
@@ -2077,6 +2079,38 @@ int pdlp_probe_stream_read(const void* buf, int64_t bytes, int reps, void* strea
     HIP_TRY(hipGetLastError());
     const size_t per = n16 / grid, read16 = per / (4 * 512) * (4 * 512) * grid;      // what the kernel really loads
     *gb_per_s = (double)read16 * 16.0 * reps / ((double)ms * 1e-3) / 1e9;
+    return PDLP_OK;
+}
+
+int pdlp_probe_gather(void* scratch, int64_t scratch_bytes, int64_t table_entries, int reps, void* stream, double* gitems_per_s)
+{
+    if (!scratch || table_entries < 1 || table_entries > (int64_t)1 << 31 || reps < 1 || !gitems_per_s || ((uintptr_t)scratch & 255u))
+        return PDLP_ERR_INVALID;
+    const int64_t tbytes = align_up(table_entries * 4 + 256, 256);
+    const int64_t items = (scratch_bytes - tbytes) / 8 / NNZ_CAP * NNZ_CAP;
+    if (items < (int64_t)NNZ_CAP * 64) return PDLP_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    float* table = (float*)scratch;
+    uint32_t* idx = (uint32_t*)((char*)scratch + tbytes);
+    float* val = (float*)(idx + items);
+    HIP_TRY(hipMemsetAsync(table, 0, (size_t)tbytes, s));
+    hipLaunchKernelGGL(k_probe_fill, dim3(grid_for(items)), dim3(BLOCK), 0, s, idx, val, items, (uint32_t)table_entries);
+    const int64_t nblk = items / NNZ_CAP;
+    const int grid = (int)(nblk < MAX_GRID ? nblk : MAX_GRID);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    float* sink = table + table_entries;               // (inside the padding of the table; never written)
+    hipLaunchKernelGGL(k_probe_gather, dim3(grid), dim3(BLOCK), 0, s, idx, val, table, items, sink);
+    HIP_TRY(hipEventRecord(e0, s));
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_probe_gather, dim3(grid), dim3(BLOCK), 0, s, idx, val, table, items, sink);
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    HIP_TRY(hipGetLastError());
+    *gitems_per_s = (double)items * reps / ((double)ms * 1e-3) / 1e9;
     return PDLP_OK;
 }
 

@@ -337,18 +337,36 @@ def gen_lp_shard(n: int, m: int, nnz_per_row: int, seed: int, comm: Comm, device
     return engine_from_shard(args, comm, precision, precondition)
 
 
-def agree_failed(dist, rank: int, world: int, failed: bool, tag: str, timeout_s: float = 60.0) -> int:
+_agree_calls = 0
+
+
+def agree_failed(dist, rank: int, world: int, failed: bool, tag: str, timeout_s: float = 60.0, seq: Optional[int] = None) -> int:
     """How many ranks failed at the point ``tag``; -1 if the ranks cannot agree within ``timeout_s``.  Out of band, over the process
     group's key-value store -- NOT a collective: a rank that raises in the middle of a solve has peers blocked inside the solve's own
     all-gathers / all-reduces, and a collective issued from its exception path would pair with one of those (undefined behaviour
     under RCCL: a hang or garbage).  Ranks that fail alike (an unsupported option, a bad instance: before any collective) post
-    their flags at once; a rank that fails alone waits ``timeout_s`` for flags that never come and gets -1."""
+    their flags at once; a rank that fails alone waits ``timeout_s`` for flags that never come and gets -1.
+    The keys carry a sequence number (``seq``; default: this process's call count -- every rank calls once per agreement point, in
+    the same order) so that a second run over the same instance names in one process group never reads the flags of the first;
+    a rank deletes its own key once it has the answer."""
     import datetime
+    global _agree_calls
+    if seq is None:
+        seq = _agree_calls
+    _agree_calls += 1
     store = dist.distributed_c10d._get_default_store()
-    store.set(f"pdlp/fail/{tag}/{rank}", "1" if failed else "0")
-    keys = [f"pdlp/fail/{tag}/{r}" for r in range(world)]
+    key = lambda r: f"pdlp/fail/{int(seq)}/{tag}/{r}"
+    keys = [key(r) for r in range(world)]
     try:
+        store.set(key(rank), "1" if failed else "0")
         store.wait(keys, datetime.timedelta(seconds=timeout_s))
+        bad = sum(int(store.get(k) == b"1") for k in keys)
     except Exception:
         return -1
-    return sum(int(store.get(k) == b"1") for k in keys)
+    try:                                   # everybody has posted; every rank read all keys before deleting only after a second wait
+        store.set(key(rank) + "/seen", "1")
+        store.wait([k + "/seen" for k in keys], datetime.timedelta(seconds=timeout_s))
+        store.delete_key(key(rank))
+    except Exception:
+        pass                               # (a store without delete, or a peer that left: the sequence number keeps later calls apart)
+    return bad

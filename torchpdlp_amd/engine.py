@@ -179,9 +179,9 @@ class PdlpEngine:
     # ---- panel-tiled matrix copies (fast path for wide gathered vectors) -------------------------------
     def tile_limits(self) -> dict:
         """what ``pdlp_attach_tiles`` accepts on this handle (the row-sum scratch and the partial-sum slots are sized at creation)"""
-        out = (C.c_int32 * 4)()
+        out = (C.c_int32 * 6)()
         N.check(self.lib.pdlp_tile_limits(self.h, out), "pdlp_tile_limits")
-        return dict(max_groups=out[0], max_blocks=out[1], rpt_max=out[2], cap=out[3])
+        return dict(max_groups=out[0], max_blocks=out[1], rpt_max=out[2], cap=out[3], nt=out[4])
 
     def _maybe_attach_tiles(self):
         """Which kernel multiplies each matrix -- decided from the shape alone, so a run (and every rank of a sharded
@@ -208,11 +208,11 @@ class PdlpEngine:
             knob = lambda name: int(os.environ[name]) if os.environ.get(name) else None      # tuning experiments
             t = _tiled.build_tiles(rp, ci, va, rows, cols, lw=knob("PDLP_TILE_LW"), rpt=knob("PDLP_TILE_RPT"),
                                    groups=knob("PDLP_TILE_GROUPS"), max_groups=lim["max_groups"],
-                                   kernel_limits=(lim["rpt_max"], lim["cap"]))
+                                   kernel_limits=(lim["rpt_max"], lim["cap"], lim["nt"]))
             if t is None or t.nblk > lim["max_blocks"]:
                 # clustered (banded, block structured): the CSR kernel, with every row block's items sorted by column
                 if t is None and os.environ.get("PDLP_SORTED", "auto") != "0":
-                    self.attach_sorted(transpose)
+                    self.attach_sorted(transpose, force=False)        # (only if the blocks' columns do cluster)
                 continue
             if mode != "time":
                 self.attach_tiles(transpose, t)
@@ -236,7 +236,7 @@ class PdlpEngine:
         b.synchronize()
         return a.elapsed_time(b) / reps
 
-    def attach_sorted(self, transpose: int, on: bool = True):
+    def attach_sorted(self, transpose: int, on: bool = True, force: bool = True):
         """Column-sorted copy of every row block's items for the CSR kernel (``pdlp_attach_sorted``): for matrices whose entries
         cluster (banded, block structured) a wave's gathers then touch a few cache lines instead of one per lane.  Same sums."""
         transpose = int(transpose)
@@ -262,6 +262,15 @@ class PdlpEngine:
         cmin = torch.full((nb.value,), big, dtype=torch.int64, device=dev).scatter_reduce_(0, bid, cl, "amin")
         cmax = torch.full((nb.value,), -1, dtype=torch.int64, device=dev).scatter_reduce_(0, bid, cl, "amax")
         ok = (lens > 0) & (lens <= 2048) & (cmax - cmin < (1 << 21))
+        if not force:
+            # Sorting pays when neighbouring sorted items share 128-byte lines.  A block whose columns are spread so thinly that sorted
+            # neighbours are >= 32 columns apart on average touches one line per item either way, and the sorted form then only costs:
+            # the extra dependent load of the block's base column and scattered LDS stores (neos3-shaped K': 24.5k -> 24.9k it/s
+            # in plain CSR order, profiles/r05_small_lp/).  Keep CSR order unless most items sit in blocks that do cluster.
+            gap = (cmax - cmin).double() / (lens - 1).clamp(min=1).double()
+            dense = ok & (gap < 32.0)
+            if float(lens[dense].sum()) < 0.5 * nnz:
+                return
         order = torch.argsort((bid << 32) | cl, stable=True)        # by (block, column); blocks stay in place
         slot = (torch.arange(nnz, device=dev) - first[bid])[order]
         sidx = (slot << 21) | (cl[order] - cmin[bid]).clamp_(0, (1 << 21) - 1)

@@ -45,13 +45,13 @@ from typing import Optional
 import torch
 
 LW_DEFAULT = 16      # panel = 65536 columns (256 KB of f32: L2 resident on every XCD)
-NT = 512             # threads per workgroup (fixed by the kernel)
+NT = 512             # threads per workgroup of the standard kernel (``Tiles.nt``: what a tile set was built for)
 RPT_MAX = 40         # float32: most rows per thread; 32-bit words of 4-bit counts per (tile, thread) = RPT_MAX/8
 CAP = 16384          # float32: items per tile (64 KB of LDS products per workgroup)
 RPT_MAX_F64 = 24     # float64: the same LDS and register budget holds half as many
 CAP_F64 = 8192
 GROUP = 256          # tiles are padded to whole groups of 4 x 64 items (interleaved, see above)
-NCU = 512            # two workgroups per CU at a time: row blocks are sized to fill whole rounds
+NCU = 512            # two workgroups of 512 threads per CU at a time: row blocks are sized to fill whole rounds
 LMAX = 15            # items of one row in one tile (4-bit counts)
 GMAX = 255           # items of 64 consecutive rows (one i of one wave) in one tile (8-bit scan fields)
 SEG = 512            # items per remainder segment (eight lanes: 64 per lane, in batches of eight)
@@ -73,6 +73,7 @@ class Tiles:
                              #   [tile][thread][4] (words 0..3, zero padded) then [tile][cw - 4][thread] (the other words)
     groups: int = 1          # workgroups sharing a row block (each walks ceil(npanel/groups) panels)
     rpt_max: int = RPT_MAX   # rows per thread the kernel instantiation for this precision supports
+    nt: int = NT             # threads per workgroup of the kernel that reads these tiles (a row block is nt*rpt rows)
     # remainder: segments of <= SEG items of the rows listed in rem_rows
     rem_rows: Optional[torch.Tensor] = None  # int32 [nr]   rows (local to this matrix) with a remainder, ascending
     rem_rptr: Optional[torch.Tensor] = None  # int32 [nr+1] their segment ranges
@@ -91,7 +92,7 @@ class Tiles:
 
     @property
     def rows_per_block(self) -> int:
-        return NT * self.rpt
+        return self.nt * self.rpt
 
     @property
     def nrem(self) -> int:
@@ -122,9 +123,9 @@ def rowsum_groups(rows: int) -> int:
     """panel groups the library's row-sum scratch has room for on a handle whose longer local side has ``rows`` rows
     (``rowsum_groups`` in csrc/pdlp_hip.hip; ``pdlp_tile_limits`` reports the same number for a live handle): splitting a
     row block's panels over several workgroups only pays while one workgroup per row block cannot fill 2 x 256 CUs"""
-    if rows <= NT * 40 * 128:
+    if rows <= 512 * 40 * 128:
         return 24               # (small shards: the local panels' groups plus those of every chunk of a chunked exchange)
-    return 8 if rows <= NT * 40 * 512 else 1
+    return 8 if rows <= 512 * 40 * 512 else 1
 
 
 def _wrap_i32(v: torch.Tensor) -> torch.Tensor:
@@ -137,17 +138,18 @@ def limits(dtype):
     return (RPT_MAX, CAP) if dtype == torch.float32 else (RPT_MAX_F64, CAP_F64)
 
 
-def choose_shape(nrows: int, nnz: int, ncols: int, lw: int, cap: int = CAP, slots: int = NCU, max_groups: int = 8,
-                 rpt_max: int = RPT_MAX):
+def choose_shape(nrows: int, nnz: int, ncols: int, lw: int, cap: int = CAP, slots: Optional[int] = None, max_groups: int = 8,
+                 rpt_max: int = RPT_MAX, nt: int = NT):
     """(rows per thread, panel groups).  Denser tiles mean fewer cache lines per gather, so take as many rows per
     workgroup as the tile capacity allows; when that leaves too few row blocks to fill the chip (few rows, e.g. one
     rank's shard), let several workgroups share a row block by splitting its panels into groups."""
     W = 1 << lw
+    slots = NCU * NT // nt if slots is None else slots               # workgroups resident at a time (1024 threads per CU)
     P = max(1, (ncols + W - 1) // W)
     per_row_panel = max(nnz / max(nrows, 1) * min(W, ncols) / max(ncols, 1), 1e-9)   # mean items of a row in a panel
     best, best_score = (1, 1), -1.0
     for rpt in range(1, rpt_max + 1):
-        rb = NT * rpt
+        rb = nt * rpt
         mean_tile = rb * min(per_row_panel, float(LMAX))
         if mean_tile + 6.0 * mean_tile ** 0.5 > cap and rpt > 1:      # keep 6 sigma below the LDS capacity
             break
@@ -199,7 +201,7 @@ def _rank_in_group(key: torch.Tensor, ngroups: int):
 
 
 def _pack(tile: torch.Tensor, row_in_block: torch.Tensor, sortcol: torch.Tensor, low: torch.Tensor, shift: int, val: torch.Tensor,
-          ntl: int, RB: int, rpt: int, rpt_max: int, extra: Optional[torch.Tensor] = None):
+          ntl: int, RB: int, rpt: int, rpt_max: int, extra: Optional[torch.Tensor] = None, NT: int = NT):
     """Lay the items of ``ntl`` tiles out the way the kernel reads them.  Items arrive in row order inside every tile (CSR
     order); ``sortcol`` orders a tile's items for the gathers; the stored word is ``(slot << shift) | low``.
     Returns (idx int32, val, extra int32 or None, padded tile sizes, count words int32 [ntl*512*CW])."""
@@ -254,7 +256,7 @@ def _pack(tile: torch.Tensor, row_in_block: torch.Tensor, sortcol: torch.Tensor,
 def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, nrows: int, ncols: int,
                 lw: Optional[int] = None, rpt: Optional[int] = None, cap: Optional[int] = None, max_chunk_nnz: int = 1 << 26,
                 groups: Optional[int] = None, max_groups: int = 8, max_rest: float = 0.30,
-                kernel_limits: Optional[tuple] = None) -> Optional[Tiles]:
+                kernel_limits: Optional[tuple] = None, nt: Optional[int] = None) -> Optional[Tiles]:
     """CSR (any row lengths, columns sorted or not) -> Tiles, or None when more than ``max_rest`` of the items would not
     fit the tiles proper (a clustered matrix: the CSR kernel is the better one).  Runs on the tensors' device with torch
     sorts (setup cost, done once per matrix)."""
@@ -264,13 +266,14 @@ def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, n
     # (rows per thread, items per tile) of the kernel that will read the tiles: the library's build says (pdlp_tile_limits)
     rpt_max, cap_max = limits(val.dtype) if kernel_limits is None else (int(kernel_limits[0]), int(kernel_limits[1]))
     cap = cap_max if cap is None else cap
+    NT = int(nt) if nt is not None else (int(kernel_limits[2]) if kernel_limits is not None and len(kernel_limits) > 2 else globals()["NT"])
     CW = rpt_max // 8
     nnz = int(colidx.numel())
     if lw is None:
         lw = choose_lw(nrows, nnz, ncols)
     W = 1 << lw
     if rpt is None:
-        rpt, g_auto = choose_shape(nrows, nnz, ncols, lw, cap, rpt_max=rpt_max, max_groups=max(1, min(8, int(max_groups))))
+        rpt, g_auto = choose_shape(nrows, nnz, ncols, lw, cap, rpt_max=rpt_max, max_groups=max(1, min(8, int(max_groups))), nt=NT)
         groups = g_auto if groups is None else groups
     groups = 1 if groups is None else int(groups)
     if not 1 <= rpt <= rpt_max:
@@ -348,7 +351,7 @@ def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, n
                 del drop
             del keep, rloc, rblk
             lcol = cols & (W - 1)
-            p_idx, p_val, _, tsz_pad, p_cnt = _pack(tile, rib, lcol, lcol, lw, v, ntl, RB, rpt, rpt_max)
+            p_idx, p_val, _, tsz_pad, p_cnt = _pack(tile, rib, lcol, lcol, lw, v, ntl, RB, rpt, rpt_max, NT=NT)
             parts_idx.append(p_idx)
             parts_val.append(p_val)
             parts_cnt.append(p_cnt)
@@ -362,8 +365,8 @@ def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, n
     cat = lambda parts, dt: (parts[0] if len(parts) == 1 else torch.cat(parts)) if parts else torch.zeros(0, dtype=dt, device=dev)
     idx_all, val_all = cat(parts_idx, torch.int32), cat(parts_val, val.dtype)
     del parts_idx, parts_val
-    t = Tiles(lw, rpt, cap, NB, P, nrows, ncols, idx_all, val_all, tile_ptr, _count_layout(cat(parts_cnt, torch.int32), NB * P, CW),
-              normalize_groups(groups, P, max(1, int(max_groups))), rpt_max)
+    t = Tiles(lw, rpt, cap, NB, P, nrows, ncols, idx_all, val_all, tile_ptr, _count_layout(cat(parts_cnt, torch.int32), NB * P, CW, NT),
+              normalize_groups(groups, P, max(1, int(max_groups))), rpt_max, NT)
     t.stats = dict(nnz=nnz, tiled=nnz - n_over, remainder=0)
     if n_over == 0:
         return t
@@ -389,11 +392,9 @@ def build_tiles(rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, n
     return t
 
 
-def _count_layout(cnt_tm: torch.Tensor, ntiles: int, CW: int) -> torch.Tensor:
+def _count_layout(cnt_tm: torch.Tensor, ntiles: int, CW: int, NT: int = NT) -> torch.Tensor:
     """thread-major count words [tile][thread][CW] -> the kernel's layout: [tile][thread][4] (words 0..3 as one 16-byte entry per
     thread, zero padded when CW < 4), then [tile][CW - 4][thread] (k_tiled_fused, load_counts)"""
-    if os.environ.get("PDLP_CNT_LAYOUT") == "thread":      # A/B timing against a -DPDLP_COUNTS_THREAD_MAJOR build only
-        return cnt_tm
     c = cnt_tm.view(ntiles, NT, CW)
     a = torch.zeros(ntiles, NT, 4, dtype=torch.int32, device=c.device)
     a[:, :, :min(CW, 4)] = c[:, :, :4]
@@ -403,8 +404,8 @@ def _count_layout(cnt_tm: torch.Tensor, ntiles: int, CW: int) -> torch.Tensor:
 
 
 def _tile_count_words(t: Tiles, tile: int) -> torch.Tensor:
-    """[512][cw] count words of one tile out of the kernel's layout"""
-    CW, ntiles = t.cw, t.nblk * t.npanel
+    """[nt][cw] count words of one tile out of the kernel's layout"""
+    CW, ntiles, NT = t.cw, t.nblk * t.npanel, t.nt
     a = t.cnt[tile * NT * 4:(tile + 1) * NT * 4].view(NT, 4)[:, :min(CW, 4)]
     if CW <= 4:
         return a
@@ -413,8 +414,8 @@ def _tile_count_words(t: Tiles, tile: int) -> torch.Tensor:
 
 
 def tile_row_counts(t: Tiles, tile: int) -> torch.Tensor:
-    """items of each of the tile's 512*rpt rows (unpacks the nibbles)"""
-    CW = t.cw
+    """items of each of the tile's nt*rpt rows (unpacks the nibbles)"""
+    CW, NT = t.cw, t.nt
     w = _tile_count_words(t, tile).reshape(-1).long() & 0xFFFFFFFF
     shifts = (torch.arange(8, device=w.device) * 4).view(1, 1, 8)
     nib = (w.view(NT, CW, 1) >> shifts) & 15
