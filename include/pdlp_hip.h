@@ -224,6 +224,18 @@ int pdlp_fixed_advance(pdlp_handle h, int iters);
  * pdlp_half_chunk does nothing.  pdlp_iterate on a handle with a communicator does all of this itself (pieces as grouped
  * in-place broadcasts on a communication stream of its own). */
 int pdlp_set_exchange_chunks(pdlp_handle h, int chunks /* 1..4 */);
+/* Producer side of the chunked exchange (round 5).  With C > 1 pieces the RESULT of a split product -- this rank's block of xbar
+ * (primal half-step) or of y (dual half-step) -- also LEAVES in pieces: the last phase of the product and the epilogue run over the
+ * row blocks that hold piece 0's rows first, then piece 1's ..., so that piece c's collective can start while the rows of the later
+ * pieces are still being multiplied (until round 4 a half-step had to finish completely before the first byte of its block left).
+ * pdlp_primal_half_piece / pdlp_dual_half_piece issue ONE piece of the half-step on the handle's stream: call them for
+ * piece = 0 .. pieces-1 in order (pieces = the plan of the exchange that FOLLOWS: pdlp_exchange_plan(h, 0) for the primal, (h, 1) for
+ * the dual half-step) and start piece c's collective after the c-th call; the half-step is complete (buffer roles, counters) after
+ * the last call.  A half-step that is not a split tiled product (CSR kernel, K'y kept by a restart check, ...) does all its work
+ * with piece 0.  Same arithmetic as pdlp_primal_half / pdlp_dual_half on the same handle (which run all pieces back to back).
+ * pdlp_iterate on a handle with a communicator does this itself.  PDLP_OPT_PRODUCER_PIECES = 0 switches it off (A/B timing). */
+int pdlp_primal_half_piece(pdlp_handle h, int adaptive, int piece, int pieces);
+int pdlp_dual_half_piece(pdlp_handle h, int adaptive, int piece, int pieces);
 /* Switches of the handle that tests and tools flip (the library itself reads no environment variables; the Python host layer maps
  * its PDLP_* test knobs onto these).  None has a counterpart in the reference; the defaults are the product path.
  *   PDLP_OPT_RUNNING_KKT  1 (default): restart checks take K x_avg, K'y_avg from running sums (pdhg.py:118-125 costs one product
@@ -231,8 +243,10 @@ int pdlp_set_exchange_chunks(pdlp_handle h, int chunks /* 1..4 */);
  *   PDLP_OPT_KTY_REUSE    1 (default): the first primal half-step after a restart check reuses the check's K'y; 0: multiplies again
  *   PDLP_OPT_GRAPH        0 (default) / 1: pdlp_iterate replays captured pairs of iterations as hipGraph launches (single-rank handles;
  *                         PDLP_ERR_STATE when the handle cannot capture)
- *   PDLP_OPT_SPLIT_SLOTS  0 (default): the library's rule; local | other << 16: panel groups of a split product (tools/split_timing.py) */
-enum { PDLP_OPT_RUNNING_KKT = 0, PDLP_OPT_KTY_REUSE = 1, PDLP_OPT_GRAPH = 2, PDLP_OPT_SPLIT_SLOTS = 3 };
+ *   PDLP_OPT_SPLIT_SLOTS  0 (default): the library's rule; local | other << 16: panel groups of a split product (tools/split_timing.py)
+ *   PDLP_OPT_PRODUCER_PIECES 1 (default): with a chunked exchange the result of a split product leaves piece by piece
+ *                         (pdlp_*_half_piece); 0: the half-step finishes before its block is exchanged (round-4 behaviour) */
+enum { PDLP_OPT_RUNNING_KKT = 0, PDLP_OPT_KTY_REUSE = 1, PDLP_OPT_GRAPH = 2, PDLP_OPT_SPLIT_SLOTS = 3, PDLP_OPT_PRODUCER_PIECES = 4 };
 int pdlp_set_option(pdlp_handle h, int option, int64_t value);
 int pdlp_exchange_plan(pdlp_handle h, int transpose, int32_t* nchunks, int64_t bounds[5]);
 int pdlp_half_chunk(pdlp_handle h, int transpose, int chunk);

@@ -421,6 +421,28 @@ def _rccl_world1_worker(rank, world, port, ret):
                     outs.append((x.clone(), y.clone(), e.scalars()["eta"], e.kkt(N.CUR, 1.0)["kkt"]))
                 assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
                 assert outs[0][2] == outs[1][2] and outs[0][3] == outs[1][3]
+            # every collective the first multi-GPU run issues, on REAL RCCL -- the chunked exchange of the library
+            # driver too: pieces as grouped in-place ncclBroadcast calls on the library's communication stream, behind the rows they
+            # are made of (producer pieces, round 5) or after the half-step (round-4 form), the step-size all-reduce queued behind the
+            # pieces on that stream, the consumer's waits on the pieces' events.  With one rank every piece is this rank's own
+            # data, so the iterates must be the bits of the handle without a communicator.
+            for pieces, producer in ((2, True), (3, True), (2, False)):
+                e1.set_exchange_chunks(pieces)
+                e1.set_producer_pieces(producer)
+                assert len(e1.exchange_plan(0)) == pieces and len(e1.exchange_plan(1)) == pieces
+                for adaptive in (True, False):
+                    outs = []
+                    for e in (e0, e1):
+                        e.set_iterate(x0, y0)
+                        e.set_step(0.02, 1.1, 1.0, 0)
+                        e.iterate(5, adaptive)
+                        e.iterate(2, adaptive)
+                        x, y = e.get_iterate(N.CUR)
+                        outs.append((x.clone(), y.clone(), e.scalars()["eta"], e.kkt(N.CUR, 1.0)["kkt"]))
+                    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (pieces, producer, adaptive)
+                    assert outs[0][2] == outs[1][2] and outs[0][3] == outs[1][3]
+            e1.set_exchange_chunks(1)
+            e1.set_producer_pieces(True)
         # per-shard generation + distributed transpose under RCCL (device-side count exchange, all_to_all_single with uneven
         # splits): with one rank the shard is the whole instance, entry for entry the one gen_lp builds
         from torchpdlp_amd.distributed import gen_lp_shard
@@ -569,6 +591,24 @@ def _libcomm_worker(rank, world, port, ret, tiled):
                     assert torch.equal(xa, xb) and torch.equal(ya, yb), (name, adaptive, chunks)
                     assert ea == eb and ka == kb, (name, adaptive, chunks, ea, eb, ka, kb)
                     assert bool(torch.isfinite(xa).all()) and float(xa.abs().sum()) > 0
+                    if chunks == 2 and tiled and name == "f32":
+                        # producer side of the chunked exchange (round 5): the result of a split product leaves piece by piece, piece
+                        # c's all-gather behind the rows it is made of.  The same products as the half-step that finishes first, up to
+                        # the grouping of the partial row sums (a piece's launch covers fewer row blocks and takes more panel groups)
+                        assert eA.producer_pieces and eB.producer_pieces
+                        res = []
+                        for on in (True, False):
+                            eA.set_producer_pieces(on)
+                            eA.set_iterate(eA.part.pad_cols(x0.to(vd))[eA.cols[0]:eA.cols[1]], eA.part.pad_rows(y0.to(vd))[eA.rows[0]:eA.rows[1]])
+                            eA.set_step(0.02, 1.1, 1.0, 0)
+                            eA.iterate(n1 + n2, False)
+                            res.append([t.clone() for t in eA.get_iterate(N.CUR)])
+                        eA.set_producer_pieces(True)
+                        for tr in (0, 1):
+                            assert eA.split_info(tr)["other_groups"] >= 2
+                        np.testing.assert_allclose(res[0][0].cpu().numpy(), res[1][0].cpu().numpy(), rtol=2e-5, atol=2e-5)
+                        np.testing.assert_allclose(res[0][1].cpu().numpy(), res[1][1].cpu().numpy(), rtol=2e-5, atol=2e-5)
+                        assert not torch.equal(res[0][0], torch.zeros_like(res[0][0]))
                     if chunks == 1:
                         whole[adaptive] = (xa, ya, ka)
                     else:

@@ -184,6 +184,10 @@ struct Schedule {
     int ph_off[MAX_PHASE] = {0}, ph_cnt[MAX_PHASE] = {0}, ph_slots[MAX_PHASE] = {0}, ph_slot0[MAX_PHASE] = {0};
     int64_t sb[MAX_PHASE] = {0};
     int chunks_done = 0;          // chunk phases of the pending product already launched (pdlp_half_chunk)
+    // the RESULT of the product travels in `nrange` pieces (the plan of the exchange that follows): piece r = the rows of the row
+    // blocks [rb_lo[r], rb_lo[r+1]); the last phase and the epilogue of a split product then run piece by piece (launch_mat)
+    int nrange = 0;
+    int rb_lo[MAX_PHASE] = {0};
 };
 
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
@@ -253,6 +257,9 @@ struct pdlp_solver {
     int xchunks;                  // chunks of the exchange of a gathered vector (pdlp_set_exchange_chunks); 1: one all-gather
     hipStream_t cstream;          // the chunks travel on this stream while the handle's stream multiplies what has arrived
     hipEvent_t ev_vec, ev_chunk[MAX_CHUNKS];
+    hipEvent_t ev_ar;               // library driver: the step-size rule's all-reduce on the communication stream has finished
+    hipEvent_t ev_row[MAX_CHUNKS];  // library driver: piece r of the vector a half-step is producing is final on the handle's stream
+    int range_sel, range_cnt;       // >= 0: the half-step being issued covers only output piece `range_sel` of `range_cnt` (pdlp_*_half_piece)
     char* ktyr;                   // [nl] float64 running K'y
     float *gdx, *gdy;             // full-length float32 difference vectors the float32 kernels gather from
     int64_t nl, ml;               // local variable / constraint counts
@@ -272,6 +279,8 @@ struct pdlp_solver {
     bool no_kty_reuse;            // PDLP_OPT_KTY_REUSE = 0: timing experiments
     int split_local, split_other; // PDLP_OPT_SPLIT_SLOTS: panel groups of a split product chosen by the caller (0: the library's rule)
     bool side_ok;                 // the library's own streams and events exist (graph replay, split products)
+    bool producer_groups;         // the launches of an output piece take more panel groups to fill the chip (default)
+    bool producer_pieces;         // PDLP_OPT_PRODUCER_PIECES (default on): results of split products leave piece by piece (Schedule::nrange)
     // running products: K x (kxb[0]) is carried along by every dual half-step and both products are summed with the
     // average's weights (kx_sum, kty_sum), so a restart check evaluates K x_cur, K x_avg and K'y_avg WITHOUT products:
     // one product (K'y_cur, kept for the next primal half-step) instead of four per check
@@ -316,6 +325,8 @@ void free_handle(pdlp_handle h)
     if (h->cstream) { (void)hipStreamSynchronize(h->cstream); (void)hipStreamDestroy(h->cstream); }
     if (h->ev_vec) (void)hipEventDestroy(h->ev_vec);
     for (auto& e : h->ev_chunk) if (e) (void)hipEventDestroy(e);
+    for (auto& e : h->ev_row) if (e) (void)hipEventDestroy(e);
+    if (h->ev_ar) (void)hipEventDestroy(h->ev_ar);
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->ev_out) (void)hipEventDestroy(h->ev_out);
     delete h;
@@ -325,22 +336,41 @@ void free_handle(pdlp_handle h)
 // rowsum[slot0 .. slot0 + vgroups); the epilogue functor is not used by these launches
 template <typename T, typename TV>
 void launch_tiled_groups(pdlp_handle h, const Schedule& s, int rows, const void* vin, hipStream_t stream, int vgroups, int vtotal,
-                         const int32_t* ptab, int slot0)
+                         const int32_t* ptab, int slot0, int b0 = 0, int nbl = -1)
 {
-    if (vtotal <= 0 || vgroups <= 0) return;
+    if (nbl < 0) nbl = s.t.nblk - b0;                     // (default: every row block)
+    if (vtotal <= 0 || vgroups <= 0 || nbl <= 0) return;
     const int ppg = (vtotal + vgroups - 1) / vgroups;
     const int groups = (vtotal + ppg - 1) / ppg;          // no group without panels
     StoreEpi<T> none{nullptr};
-    hipLaunchKernelGGL((k_tiled_fused<T, TV, StoreEpi<T>, false>), dim3(s.t.nblk * groups), dim3(TNT), 0, stream, s.t.idx,
+    hipLaunchKernelGGL((k_tiled_fused<T, TV, StoreEpi<T>, false>), dim3(nbl * groups), dim3(TNT), 0, stream, s.t.idx,
                        (const TV*)s.t.val, s.t.tile_ptr, s.t.blk_base, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, ppg, vtotal, ptab,
-                       slot0, (const T*)vin, (T*)h->rowsum, h->rs_stride, (const T*)nullptr, none, (double*)nullptr);
+                       slot0, b0, nbl, (const T*)vin, (T*)h->rowsum, h->rs_stride, (const T*)nullptr, none, (double*)nullptr);
 }
 
-// one phase of a split product (0: the own block's panels, 1 + c: the panels completed by chunk c of the exchange)
+// one phase of a split product (0: the own block's panels, 1 + c: the panels completed by chunk c of the exchange), over all row
+// blocks or over the row blocks [b0, b0 + nbl) of one output piece (the last phase of a product whose result travels in pieces)
 template <typename T, typename TV>
-void launch_phase(pdlp_handle h, const Schedule& s, int rows, const void* vin, hipStream_t stream, int phase)
+void launch_phase(pdlp_handle h, const Schedule& s, int rows, const void* vin, hipStream_t stream, int phase, int b0 = 0, int nbl = -1)
 {
-    launch_tiled_groups<T, TV>(h, s, rows, vin, stream, s.ph_slots[phase], s.ph_cnt[phase], s.ptab + s.ph_off[phase], s.ph_slot0[phase]);
+    launch_tiled_groups<T, TV>(h, s, rows, vin, stream, s.ph_slots[phase], s.ph_cnt[phase], s.ptab + s.ph_off[phase], s.ph_slot0[phase], b0, nbl);
+}
+
+// Output pieces of a split product (Schedule::nrange > 1): rows of piece r = row blocks [rb_lo[r], rb_lo[r+1]).  The k_rowsum_epilogue
+// launches of the pieces write their partial sums one after the other: piece r's first slot, and the total.
+inline int range_rows_lo(const Schedule& s, int r) { return s.rb_lo[r] * TNT * s.t.rpt; }
+inline int range_rows_hi(const Schedule& s, int r, int rows) { const int64_t e = (int64_t)s.rb_lo[r + 1] * TNT * s.t.rpt; return (int)(e < rows ? e : rows); }
+inline int range_epi_grid(const Schedule& s, int r, int rows)
+{
+    const int n = range_rows_hi(s, r, rows) - range_rows_lo(s, r);
+    return n > 0 ? grid_for(n) : 0;
+}
+inline int split_epi_grid(const Schedule& s, int rows)
+{
+    if (s.nrange <= 1) return grid_for(rows);
+    int g = 0;
+    for (int r = 0; r < s.nrange; ++r) g += range_epi_grid(s, r, rows);
+    return g;
 }
 
 // one product with K (or K') over the vector vin with the epilogue fused: T = type of vin, of the row sums and of what the
@@ -361,7 +391,9 @@ int launch_mat(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* 
         const int rows = (int)(transpose ? h->nl : h->ml);
         // the remainder (items the tile format could not hold) first: its row sums go to a dense vector the epilogue adds
         const T* extra = nullptr;
-        if (s.t.rem_rows_n > 0) {
+        if (s.t.rem_rows_n > 0 && h->range_sel > 0) {
+            extra = (const T*)(sizeof(T) == 4 && h->es == 8 ? s.t.rem_extra_f32 : s.t.rem_extra);     // (computed with piece 0 of this half-step)
+        } else if (s.t.rem_rows_n > 0) {
             T* ex = (T*)(sizeof(T) == 4 && h->es == 8 ? s.t.rem_extra_f32 : s.t.rem_extra);
             hipLaunchKernelGGL((k_rem_segments<T, TV>), dim3(grid_for((int64_t)s.t.rem_segs_n * 8)), dim3(BLOCK), 0, h->stream, s.t.rem_segs_n,
                                s.t.rem_sptr, s.t.rem_col, (const TV*)s.t.rem_val, (const T*)vin, (T*)s.t.rem_work);
@@ -372,16 +404,32 @@ int launch_mat(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* 
         if (s.t.groups == 1 && !(s.pending && h->use_split)) {
             hipLaunchKernelGGL((k_tiled_fused<T, TV, Epi, true>), dim3(s.t.nblk), dim3(TNT), 0, h->stream, s.t.idx, (const TV*)s.t.val,
                                s.t.tile_ptr, s.t.blk_base, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, s.t.npanel, s.t.npanel,
-                               (const int32_t*)nullptr, 0, (const T*)vin, (T*)h->rowsum, h->rs_stride, extra, epi, partials);
+                               (const int32_t*)nullptr, 0, 0, s.t.nblk, (const T*)vin, (T*)h->rowsum, h->rs_stride, extra, epi, partials);
         } else if (s.pending && h->use_split) {
             // the local panels were multiplied by pdlp_*_half_begin on the side stream (and the first chunks' panels by
-            // pdlp_half_chunk as they arrived); now the remaining chunks' panels, then the sum over all slots in fixed order
+            // pdlp_half_chunk as they arrived); now the remaining chunks' panels, then the sum over all slots in fixed order.
+            // If the RESULT travels in pieces (nrange > 1: the next exchange is chunked), the last phase and the epilogue run piece
+            // by piece -- the row blocks of piece 0, its epilogue, an event; then piece 1 ... -- so that a piece's collective can
+            // start while the rows of the later pieces are still being multiplied.  h->range_sel >= 0: only that piece (the caller
+            // issues the piece's collective after every call), else all of them.
             Schedule& sm = transpose ? h->sKT : h->sK;
-            for (int ph = 1 + sm.chunks_done; ph < s.nphase; ++ph) launch_phase<T, TV>(h, s, rows, vin, h->stream, ph);
-            sm.chunks_done = 0;
-            HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_out, 0));
-            hipLaunchKernelGGL((k_rowsum_epilogue<T, Epi>), dim3(grid_for(rows)), dim3(BLOCK), 0, h->stream, (const T*)h->rowsum,
-                               s.slotsA + s.slotsB, h->rs_stride, rows, extra, epi, partials);
+            const int R = s.nrange > 1 ? s.nrange : 1, last = s.nphase - 1;
+            const int r_from = h->range_sel < 0 ? 0 : h->range_sel, r_to = h->range_sel < 0 ? R : h->range_sel + 1;
+            if (r_from == 0) {
+                for (int ph = 1 + sm.chunks_done; ph < (R > 1 ? last : s.nphase); ++ph) launch_phase<T, TV>(h, s, rows, vin, h->stream, ph);
+                sm.chunks_done = 0;
+            }
+            int pofs = 0;
+            for (int r = 0; r < r_from && R > 1; ++r) pofs += range_epi_grid(s, r, rows);
+            for (int r = r_from; r < r_to && r < R; ++r) {
+                if (R > 1) launch_phase<T, TV>(h, s, rows, vin, h->stream, last, s.rb_lo[r], s.rb_lo[r + 1] - s.rb_lo[r]);
+                if (r == 0) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_out, 0));
+                const int lo = R > 1 ? range_rows_lo(s, r) : 0, hi = R > 1 ? range_rows_hi(s, r, rows) : rows;
+                if (hi > lo)
+                    hipLaunchKernelGGL((k_rowsum_epilogue<T, Epi>), dim3(grid_for(hi - lo)), dim3(BLOCK), 0, h->stream, (const T*)h->rowsum,
+                                       s.slotsA + s.slotsB, h->rs_stride, hi, extra, epi, partials + (size_t)pofs * NACC, lo);
+                pofs += R > 1 ? range_epi_grid(s, r, rows) : 0;
+            }
         } else {
             launch_tiled_groups<T, TV>(h, s, rows, vin, h->stream, s.t.groups, s.t.npanel, (const int32_t*)nullptr, 0);
             hipLaunchKernelGGL((k_rowsum_epilogue<T, Epi>), dim3(grid_for(rows)), dim3(BLOCK), 0, h->stream, (const T*)h->rowsum,
@@ -421,7 +469,19 @@ inline int grid_of(const Schedule& s, int64_t rows)
 {
     if (s.nblk == 0) return 0;
     if (!s.tiled) return s.grid + (s.nlong > 0 ? s.lgrid : 0);
-    return (s.t.groups == 1 && !s.pending) ? s.t.nblk : grid_for(rows);   // split tiles: the partial sums come from k_rowsum_epilogue
+    if (s.t.groups == 1 && !s.pending) return s.t.nblk;
+    return s.pending ? split_epi_grid(s, (int)rows) : grid_for(rows);      // split tiles: the partial sums come from k_rowsum_epilogue
+}
+
+// A half-step issued piece by piece (pdlp_*_half_piece: h->range_sel = the piece, h->range_cnt = their number).  Only a split product
+// whose result travels in pieces really runs piece by piece (launch_mat); every other form of the half-step does all its work with
+// piece 0 and nothing afterwards.  The state changes that end a half-step (buffer roles, counters) wait for the last piece.
+struct PieceCtl { bool skip, finish; };
+inline PieceCtl piece_ctl(pdlp_handle h, const Schedule& s, bool product_is_launched = true)
+{
+    const bool piece_mode = h->range_sel >= 0;
+    const bool capable = product_is_launched && s.tiled && s.pending && s.nrange > 1;
+    return PieceCtl{piece_mode && !capable && h->range_sel > 0, !piece_mode || h->range_sel >= h->range_cnt - 1};
 }
 
 template <typename T> T* xloc(pdlp_handle h, int ix) { return (T*)h->xb[ix] + h->p.col0; }
@@ -447,6 +507,8 @@ template <typename T> int primal_half_t(pdlp_handle h, int adaptive)
     // restart point) or the restart check's flush has already added it
     // (not under graph replay: a captured launch would freeze this decision)
     T* ksum = (h->since_reset > 0 && !h->kty_tail_done && !h->sums_broken && !h->no_running && !h->graph_ok) ? (T*)h->kty_sum : nullptr;
+    const PieceCtl pc = piece_ctl(h, h->sKT, src < 0);
+    if (pc.skip) return PDLP_OK;                             // (all of this half-step went out with piece 0)
     if (adaptive) {
         PrimalEpi<T, true> e{xloc<T>(h, h->ix_cur), xloc<T>(h, h->ix_prev), (T*)h->xbar + h->p.col0, (const T*)h->p.c,
                              (const T*)h->p.l, (const T*)h->p.u, (T*)h->x_sum, sc, ksum};
@@ -457,7 +519,8 @@ template <typename T> int primal_half_t(pdlp_handle h, int adaptive)
         h->last_gridA = grid_of(h->sKT, h->nl);
         h->use_split = true;
         const int rc = launch_csr<T>(h, true, h->yb[h->ix_cur], e, h->partA);
-        h->use_split = false; h->sKT.pending = false;
+        h->use_split = false;
+        if (pc.finish) h->sKT.pending = false;
         return rc;
     }
     PrimalEpi<T, false> e{xloc<T>(h, h->ix_cur), xloc<T>(h, h->ix_prev), (T*)h->xbar + h->p.col0, (const T*)h->p.c,
@@ -465,7 +528,8 @@ template <typename T> int primal_half_t(pdlp_handle h, int adaptive)
     if (src >= 0) return primal_from_kty<T>(h, src, e);
     h->use_split = true;
     const int rc = launch_csr<T>(h, true, h->yb[h->ix_cur], e, h->partA);
-    h->use_split = false; h->sKT.pending = false;
+    h->use_split = false;
+    if (pc.finish) h->sKT.pending = false;
     return rc;
 }
 
@@ -482,7 +546,11 @@ template <typename T> int dual_half_t(pdlp_handle h, int adaptive)
     int rc;
     if (!h->kx_valid && (rc = refresh_kx_t<T>(h)) != PDLP_OK) return rc;      // K x of the current x: carried along from here on
     T* ksum = (h->sums_broken || h->no_running || h->graph_ok) ? nullptr : (T*)h->kx_sum;
-    if (adaptive) {
+    const PieceCtl pc = piece_ctl(h, h->sK);
+    rc = PDLP_OK;
+    if (pc.skip) {
+        // (all of this half-step went out with piece 0)
+    } else if (adaptive) {
         DualEpi<T, true> e{yloc<T>(h, h->ix_cur), yloc<T>(h, h->ix_prev), (const T*)h->p.q, (T*)h->y_sum, (T*)h->kxb[0],
                            h->sc, h->ineq_end, ksum};
         h->last_gridB = grid_of(h->sK, h->ml);
@@ -494,8 +562,10 @@ template <typename T> int dual_half_t(pdlp_handle h, int adaptive)
         h->use_split = true;
         rc = launch_csr<T>(h, false, h->xbar, e, h->partB);
     }
-    h->use_split = false; h->sK.pending = false;
-    if (rc != PDLP_OK) return rc;
+    h->use_split = false;
+    if (rc != PDLP_OK) { h->sK.pending = false; return rc; }
+    if (!pc.finish) return PDLP_OK;                          // (more pieces of this half-step to come)
+    h->sK.pending = false;
     ++h->since_reset;
     h->kty_tail_done = false; h->avg_products = false;
     const int t = h->ix_cur;   // the freshly written buffers become current, the old ones previous
@@ -594,6 +664,7 @@ int configure_split(pdlp_handle h, bool transpose)
     s.loc_pa = s.loc_pb = s.slotsA = s.slotsB = 0;
     s.pending = false;
     s.nphase = 0; s.chunks_done = 0;
+    s.nrange = 0;
     if (!s.tiled) return PDLP_OK;
     const int64_t lo = transpose ? h->p.row0 : h->p.col0, hi = transpose ? h->p.row1 : h->p.col1;
     const int64_t total = transpose ? h->p.m : h->p.n;
@@ -604,6 +675,22 @@ int configure_split(pdlp_handle h, bool transpose)
     const int nloc = pb - pa, nrem = npanel - nloc;
     if (nloc <= 0 || nrem <= 0 || h->rs_groups < 2 || !s.ptab || npanel > s.ptab_cap || B <= 0 || lo % B != 0) return PDLP_OK;
     const int C = plan_bounds(B, h->xchunks, s.sb);
+    // The RESULT of this product (this rank's block of y for K, of xbar for K') is the input of the other product and travels in
+    // the pieces of THAT exchange: elements [so[r], so[r+1]) of the block = piece r.  With more than one piece the last phase and
+    // the epilogue run piece by piece (launch_mat): the row blocks that hold piece r's rows, then piece r + 1's.
+    const int64_t rows_out = transpose ? h->nl : h->ml;
+    const int64_t rbk = (int64_t)TNT * s.t.rpt;
+    int64_t so[MAX_PHASE];
+    const int R = h->producer_pieces ? plan_bounds(rows_out, h->xchunks, so) : 1;
+    int nb_max = s.t.nblk;
+    if (R > 1) {
+        nb_max = 0;
+        for (int r = 0; r <= R; ++r) {
+            const int64_t b = r == R ? s.t.nblk : (so[r] + rbk - 1) / rbk;
+            s.rb_lo[r] = (int)(b < s.t.nblk ? b : s.t.nblk);
+        }
+        for (int r = 0; r < R; ++r) nb_max = (s.rb_lo[r + 1] - s.rb_lo[r]) > nb_max ? (s.rb_lo[r + 1] - s.rb_lo[r]) : nb_max;
+    }
     // a panel is complete once the last of its foreign entries has arrived
     std::vector<int> phase((size_t)npanel);
     int cnt[MAX_PHASE] = {0};
@@ -653,7 +740,15 @@ int configure_split(pdlp_handle h, bool transpose)
         if (a < 1 || left < C) return PDLP_OK;
         g[0] = norm(a, nloc);
         int want[MAX_PHASE] = {0}, sum = 0;
-        for (int c = 0; c < C; ++c) { want[1 + c] = cnt[1 + c] > 0 ? (fit < cnt[1 + c] ? fit : cnt[1 + c]) : 0; sum += want[1 + c]; }
+        // (the last phase of a product whose result travels in pieces is launched piece by piece: each launch covers only nb_max row
+        //  blocks and needs proportionally more groups to fill the chip)
+        int fit_last = R > 1 && nb_max > 0 && h->producer_groups ? round_slots / nb_max : fit;
+        fit_last = fit_last < 1 ? 1 : fit_last;
+        for (int c = 0; c < C; ++c) {
+            const int f = c == C - 1 ? fit_last : fit;
+            want[1 + c] = cnt[1 + c] > 0 ? (f < cnt[1 + c] ? f : cnt[1 + c]) : 0;
+            sum += want[1 + c];
+        }
         for (int c = 0; c < C; ++c) {
             int w = want[1 + c];
             if (sum > left && w > 0) { w = (int)((int64_t)w * left / sum); w = w < 1 ? 1 : w; }
@@ -676,6 +771,7 @@ int configure_split(pdlp_handle h, bool transpose)
     s.loc_pa = pa; s.loc_pb = pb;
     s.slotsA = g[0];
     s.slotsB = slot - g[0];
+    s.nrange = (R > 1 && C > 1) ? R : 0;          // (one exchange piece = one all-gather: nothing to send early)
     return PDLP_OK;
 }
 
@@ -745,6 +841,7 @@ template <bool ADAPT> int delta_primal_half_a(pdlp_handle h)
                             (const double*)h->p.l, (const double*)h->p.u, (double*)h->x_sum, (double*)h->ktyr, h->sc};
     if (h->dy_folded && !h->sKT.pending) {
         // K'y of the current y is already in the anchor (a restart check folded dy in, or the anchors are fresh): vector pass
+        if (h->range_sel > 0) return PDLP_OK;                // (issued piece by piece: all of it went out with piece 0)
         h->last_gridA = h->nl > 0 ? grid_for(h->nl) : 0;
         if (h->nl == 0) return PDLP_OK;
         hipLaunchKernelGGL((k_rowsum_epilogue<float, DeltaPrimalEpi<ADAPT>>), dim3(grid_for(h->nl)), dim3(BLOCK), 0, h->stream,
@@ -752,11 +849,16 @@ template <bool ADAPT> int delta_primal_half_a(pdlp_handle h)
         HIP_TRY(hipGetLastError());
         return PDLP_OK;
     }
+    const PieceCtl pc = piece_ctl(h, h->sKT);
+    if (pc.skip) return PDLP_OK;
     h->last_gridA = grid_of(h->sKT, h->nl);
     h->use_split = true;
     rc = launch_mat<float, float, DeltaPrimalEpi<ADAPT>>(h, true, h->gdy, e, h->partA);
-    h->use_split = false; h->sKT.pending = false;
-    h->dy_folded = true;       // (the anchor now belongs to the current y)
+    h->use_split = false;
+    if (pc.finish || rc != PDLP_OK) {
+        h->sKT.pending = false;
+        h->dy_folded = true;   // (the anchor now belongs to the current y)
+    }
     return rc;
 }
 
@@ -764,11 +866,17 @@ template <bool ADAPT> int delta_dual_half_a(pdlp_handle h)
 {
     DeltaDualEpi<ADAPT> e{(const double*)yloc<double>(h, h->ix_cur), yloc<double>(h, h->ix_prev), h->gdy + h->p.row0, (const double*)h->p.q,
                           (double*)h->y_sum, (double*)h->kxb[0], h->sc, h->ineq_end};
-    h->last_gridB = grid_of(h->sK, h->ml);
-    h->use_split = true;
-    const int rc = launch_mat<float, float, DeltaDualEpi<ADAPT>>(h, false, h->gdx, e, h->partB);
-    h->use_split = false; h->sK.pending = false;
-    if (rc != PDLP_OK) return rc;
+    const PieceCtl pc = piece_ctl(h, h->sK);
+    int rc = PDLP_OK;
+    if (!pc.skip) {
+        h->last_gridB = grid_of(h->sK, h->ml);
+        h->use_split = true;
+        rc = launch_mat<float, float, DeltaDualEpi<ADAPT>>(h, false, h->gdx, e, h->partB);
+        h->use_split = false;
+    }
+    if (rc != PDLP_OK) { h->sK.pending = false; return rc; }
+    if (!pc.finish) return PDLP_OK;
+    h->sK.pending = false;
     const int t = h->ix_cur;
     h->ix_cur = h->ix_prev;
     h->ix_prev = t;
@@ -1103,7 +1211,7 @@ int64_t layout(const pdlp_problem* p, int64_t nnzK, int64_t nnzKT, int64_t* offs
     offs[k++] = c.take(nl * es);                                  // 9     x_last
     offs[k++] = c.take(ml * es);                                  // 10    y_last
     for (int i = 0; i < 3; ++i) offs[k++] = c.take(ml * es);     // 11..13 kx caches
-    const int64_t pgrid = MAX_GRID + LONG_GRID + (nl > ml ? nl : ml) / TNT + 2;  // CSR grid (+ long rows), or one workgroup per >= 512 rows (tiled, rpt >= 1)
+    const int64_t pgrid = (int64_t)MAX_GRID * MAX_CHUNKS + LONG_GRID + (nl > ml ? nl : ml) / TNT + 2;  // CSR grid (+ long rows), one workgroup per >= 512 rows (tiled, rpt >= 1), or the epilogue launches of up to MAX_CHUNKS output pieces
     offs[k++] = c.take(pgrid * NACC * 8);                         // 14    partA
     offs[k++] = c.take(pgrid * NACC * 8);                         // 15    partB
     offs[k++] = c.take(PDLP_NRED * 8);                            // 16    red
@@ -1158,7 +1266,7 @@ int read_last_rowptr(const int64_t* rp, int64_t rows, int64_t* nnz, hipStream_t 
 // ================================================================================================
 extern "C" {
 
-int pdlp_abi_version(void) { return 16; }  // 16: pdlp_set_option (the library reads no environment variables), pdlp_mv_product, pdlp_mv_combine, pdlp_vec_sqdist, pdlp_probe_gather, pdlp_tile_limits reports the threads per workgroup; 15: 64-bit row pointers, row-block bases of the tiles and schedule offsets (more than 2^31 non-zeros per handle); 14: pdlp_probe_stream_read; 13: chunked exchange (pdlp_set_exchange_chunks, pdlp_exchange_plan, pdlp_half_chunk); 12: count words of a tile laid out for coalesced loads; 11: pdlp_comm_load; 10: pdlp_set_anchors; 9: pdlp_attach_sorted; 8: running products, pdlp_flush_average(h, adaptive); 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
+int pdlp_abi_version(void) { return 16; }  // 16: pdlp_set_option (the library reads no environment variables), pdlp_mv_product, pdlp_mv_combine, pdlp_vec_sqdist, pdlp_probe_gather, pdlp_tile_limits reports the threads per workgroup, pdlp_primal_half_piece / pdlp_dual_half_piece (results of split products leave piece by piece); 15: 64-bit row pointers, row-block bases of the tiles and schedule offsets (more than 2^31 non-zeros per handle); 14: pdlp_probe_stream_read; 13: chunked exchange (pdlp_set_exchange_chunks, pdlp_exchange_plan, pdlp_half_chunk); 12: count words of a tile laid out for coalesced loads; 11: pdlp_comm_load; 10: pdlp_set_anchors; 9: pdlp_attach_sorted; 8: running products, pdlp_flush_average(h, adaptive); 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
 
 const char* pdlp_strerror(int code)
 {
@@ -1213,6 +1321,8 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     h->comm = nullptr; h->comm_rank = 0; h->comm_size = 1;
     h->xchunks = 1; h->cstream = nullptr; h->ev_vec = nullptr;
     for (auto& e : h->ev_chunk) e = nullptr;
+    for (auto& e : h->ev_row) e = nullptr;
+    h->ev_ar = nullptr;
     h->delta = false; h->anchors_valid = false; h->dy_folded = false;
     h->nl = nl;
     h->ml = ml;
@@ -1242,9 +1352,11 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     h->kty_cur = -1;
     h->no_kty_reuse = false;
     h->split_local = h->split_other = 0;
+    h->producer_pieces = true; h->producer_groups = true;
+    h->range_sel = -1; h->range_cnt = 1;
     h->rs_stride = (nl > ml ? nl : ml) + (int64_t)TNT * TRPT_MAX_ANY;
     h->rs_groups = (int)rowsum_groups(nl > ml ? nl : ml);
-    h->part_blocks = MAX_GRID + LONG_GRID + (nl > ml ? nl : ml) / TNT + 2;
+    h->part_blocks = (int64_t)MAX_GRID * MAX_CHUNKS + LONG_GRID + (nl > ml ? nl : ml) / TNT + 2;
     h->kx_valid = false; h->cand_valid[0] = h->cand_valid[1] = false;
     h->last_gridA = h->last_gridB = 0;
     for (auto& g : h->graphs) g.valid = false;
@@ -1465,6 +1577,21 @@ int pdlp_dual_half(pdlp_handle h, int adaptive)
     return DISPATCH(h, dual_half_t, h, adaptive);
 }
 
+// One output piece of a half-step (see pdlp_hip.h).  Pieces in order, 0 .. pieces-1; the half-step is complete after the last.
+static int half_piece(pdlp_handle h, bool dual, int adaptive, int piece, int pieces)
+{
+    if (!h || pieces < 1 || pieces > MAX_CHUNKS || piece < 0 || piece >= pieces) return PDLP_ERR_INVALID;
+    h->range_sel = piece;
+    h->range_cnt = pieces;
+    const int rc = dual ? pdlp_dual_half(h, adaptive) : pdlp_primal_half(h, adaptive);
+    h->range_sel = -1;
+    h->range_cnt = 1;
+    return rc;
+}
+
+int pdlp_primal_half_piece(pdlp_handle h, int adaptive, int piece, int pieces) { return half_piece(h, false, adaptive, piece, pieces); }
+int pdlp_dual_half_piece(pdlp_handle h, int adaptive, int piece, int pieces) { return half_piece(h, true, adaptive, piece, pieces); }
+
 int pdlp_primal_half_begin(pdlp_handle h)
 {
     if (!h) return PDLP_ERR_INVALID;
@@ -1499,6 +1626,14 @@ int pdlp_set_option(pdlp_handle h, int option, int64_t value)
             drop_graphs(h);
             h->graph_ok = value != 0 && h->side_ok && !h->comm;
             return (value != 0 && !h->graph_ok) ? PDLP_ERR_STATE : PDLP_OK;
+        case PDLP_OPT_PRODUCER_PIECES: {
+            h->producer_pieces = value != 0;
+            h->producer_groups = value != 2;          // (2: the pieces' launches keep the phase's group count -- A/B timing)
+            drop_graphs(h);
+            int rc = configure_split(h, false);
+            if (rc == PDLP_OK) rc = configure_split(h, true);
+            return rc;
+        }
         case PDLP_OPT_SPLIT_SLOTS: {
             const int a = (int)(value & 0xffff), b = (int)((value >> 16) & 0xffff);
             if (value != 0 && (a < 1 || b < 1 || a + b > h->rs_groups)) return PDLP_ERR_INVALID;
@@ -1666,6 +1801,24 @@ int comm_all_gather(pdlp_handle h, void* full, int64_t count, bool f32)
 
 // the exchange of one gathered vector in the chunks of its product's plan: chunk c = elements [sb[c], sb[c+1]) of every rank's
 // block, as one group of in-place broadcasts (one root per rank) on the communication stream; ev_chunk[c] marks its arrival
+int comm_exchange_piece(pdlp_handle h, int c, const int64_t* sb, void* full, int64_t block, bool f32, hipEvent_t ready)
+{
+    const size_t esz = f32 ? 4 : 8;
+    HIP_TRY(hipStreamWaitEvent(h->cstream, ready, 0));          // this rank's part of the piece is final
+    const int64_t lo = sb[c], cnt = sb[c + 1] - sb[c];
+    if (cnt > 0) {
+        RCCL_TRY(g_rccl.GroupStart());
+        for (int q = 0; q < h->comm_size; ++q) {
+            char* ptr = (char*)full + ((size_t)q * block + lo) * esz;
+            const ncclResult_t r = g_rccl.Broadcast(ptr, ptr, (size_t)cnt, f32 ? ncclFloat32 : ncclFloat64, q, h->comm, h->cstream);
+            if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); g_rccl.last_error = (int)r; return PDLP_ERR_COMM; }
+        }
+        RCCL_TRY(g_rccl.GroupEnd());
+    }
+    HIP_TRY(hipEventRecord(h->ev_chunk[c], h->cstream));
+    return PDLP_OK;
+}
+
 int comm_exchange_chunked(pdlp_handle h, int C, const int64_t* sb, void* full, int64_t block, bool f32)
 {
     const size_t esz = f32 ? 4 : 8;
@@ -1690,7 +1843,7 @@ int comm_exchange_chunked(pdlp_handle h, int C, const int64_t* sb, void* full, i
 // one half-step of a sharded iteration with the exchange of its input in front: K xbar (transpose 0) or K'y (1, not after the
 // last iteration of the call).  Chunked plans: the chunks travel on the communication stream, and the handle's stream multiplies
 // the panels a chunk completes as soon as it has arrived; the last chunk's panels, the sum and the epilogue are the half-step.
-int sharded_exchange_and_begin(pdlp_handle h, bool transpose, int adaptive, bool begin)
+int sharded_exchange_and_begin(pdlp_handle h, bool transpose, int adaptive, bool begin, bool pieces_sent = false)
 {
     int rc;
     const bool vec32 = h->p.dtype == PDLP_F32;
@@ -1704,12 +1857,40 @@ int sharded_exchange_and_begin(pdlp_handle h, bool transpose, int adaptive, bool
     const int C = plan_bounds(block, h->xchunks, sb);
     const bool chunked = C > 1 && h->cstream && g_rccl.Broadcast && g_rccl.GroupStart && g_rccl.GroupEnd;
     if (!chunked) return comm_all_gather(h, full, block, f32);
-    if ((rc = comm_exchange_chunked(h, C, sb, full, block, f32)) != PDLP_OK) return rc;
+    // (pieces_sent: the half-step that produced the vector was issued piece by piece and every piece's broadcasts went out behind
+    //  its rows -- sharded_half_in_pieces; only the consumer's side is left to do)
+    if (!pieces_sent && (rc = comm_exchange_chunked(h, C, sb, full, block, f32)) != PDLP_OK) return rc;
     for (int c = 0; c + 1 < C; ++c) {
         HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_chunk[c], 0));
         if ((rc = pdlp_half_chunk(h, transpose ? 1 : 0, c)) != PDLP_OK) return rc;
     }
     HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_chunk[C - 1], 0));
+    return PDLP_OK;
+}
+
+// A half-step whose result travels in pieces: piece r's rows (last phase of the product + epilogue), an event, and piece r's
+// broadcasts on the communication stream behind that event -- they run while piece r + 1's rows are still being multiplied.
+// Returns (through *sent) whether the pieces went out this way; if not, the caller exchanges the vector after the half-step.
+// The shape of the collectives is the plan's alone: every rank issues the same groups whether or not its own product is split.
+int sharded_half_in_pieces(pdlp_handle h, bool dual, int adaptive, bool* sent)
+{
+    int rc;
+    *sent = false;
+    const bool vec32 = h->p.dtype == PDLP_F32;
+    // the vector this half-step writes and the exchange it feeds: primal -> xbar (input of K xbar), dual -> y (input of K'y)
+    void* full = dual ? (h->delta ? (void*)h->gdy : (void*)h->yb[h->ix_prev]) : (h->delta ? (void*)h->gdx : (void*)h->xbar);
+    const int64_t block = dual ? h->ml : h->nl;
+    const bool f32 = h->delta || vec32;
+    int64_t sb[MAX_PHASE];
+    const int C = plan_bounds(block, h->xchunks, sb);
+    const bool chunked = C > 1 && h->cstream && h->producer_pieces && g_rccl.Broadcast && g_rccl.GroupStart && g_rccl.GroupEnd;
+    if (!chunked) return dual ? pdlp_dual_half(h, adaptive) : pdlp_primal_half(h, adaptive);
+    for (int c = 0; c < C; ++c) {
+        if ((rc = half_piece(h, dual, adaptive, c, C)) != PDLP_OK) return rc;
+        HIP_TRY(hipEventRecord(h->ev_row[c], h->stream));
+        if ((rc = comm_exchange_piece(h, c, sb, full, block, f32, h->ev_row[c])) != PDLP_OK) return rc;
+    }
+    *sent = true;
     return PDLP_OK;
 }
 
@@ -1726,13 +1907,28 @@ int iterate_sharded(pdlp_handle h, int iters, int adaptive)
         if ((rc = delta_refresh(h)) != PDLP_OK) return rc;
     }
     for (int it = 0; it < iters; ++it) {
-        if ((rc = pdlp_primal_half(h, adaptive)) != PDLP_OK) return rc;
-        if ((rc = sharded_exchange_and_begin(h, false, adaptive, true)) != PDLP_OK) return rc;      // xbar (delta mode: x+ - x)
-        if ((rc = pdlp_dual_half(h, adaptive)) != PDLP_OK) return rc;
+        bool sent = false;
+        if ((rc = sharded_half_in_pieces(h, false, adaptive, &sent)) != PDLP_OK) return rc;
+        if ((rc = sharded_exchange_and_begin(h, false, adaptive, true, sent)) != PDLP_OK) return rc;      // xbar (delta mode: x+ - x)
+        if ((rc = sharded_half_in_pieces(h, true, adaptive, &sent)) != PDLP_OK) return rc;
+        // the step-size rule's three sums: with the pieces on the communication stream the all-reduce queues up behind them there
+        // and runs while the handle's stream multiplies the panels the pieces complete (same sums, same values: only the order in
+        // which independent work is enqueued changes)
+        const bool ar_early = adaptive && sent && h->ev_ar;
+        if (ar_early) {
+            if ((rc = pdlp_adaptive_reduce(h)) != PDLP_OK) return rc;
+            HIP_TRY(hipEventRecord(h->ev_vec, h->stream));
+            HIP_TRY(hipStreamWaitEvent(h->cstream, h->ev_vec, 0));
+            RCCL_TRY(g_rccl.AllReduce(h->red, h->red, 3, ncclFloat64, ncclSum, h->comm, h->cstream));
+            HIP_TRY(hipEventRecord(h->ev_ar, h->cstream));
+        }
         // the new y (delta mode: y+ - y) -- final: a rejected adaptive step is kept, quirk Q1; its product starts only if
         // another iteration follows in this call
-        if ((rc = sharded_exchange_and_begin(h, true, adaptive, it + 1 < iters)) != PDLP_OK) return rc;
-        if (adaptive) {
+        if ((rc = sharded_exchange_and_begin(h, true, adaptive, it + 1 < iters, sent)) != PDLP_OK) return rc;
+        if (ar_early) {
+            HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_ar, 0));
+            if ((rc = pdlp_adaptive_update(h)) != PDLP_OK) return rc;
+        } else if (adaptive) {
             if ((rc = pdlp_adaptive_reduce(h)) != PDLP_OK) return rc;
             RCCL_TRY(g_rccl.AllReduce(h->red, h->red, 3, ncclFloat64, ncclSum, h->comm, h->stream));
             if ((rc = pdlp_adaptive_update(h)) != PDLP_OK) return rc;
@@ -1775,6 +1971,8 @@ int pdlp_comm_init(pdlp_handle h, const char* rccl_path, const void* id128, int 
         bool ok = hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking) == hipSuccess &&
                   hipEventCreateWithFlags(&h->ev_vec, hipEventDisableTiming) == hipSuccess;
         for (auto& e : h->ev_chunk) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        for (auto& e : h->ev_row) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&h->ev_ar, hipEventDisableTiming) == hipSuccess;
         if (!ok) { if (h->cstream) (void)hipStreamDestroy(h->cstream); h->cstream = nullptr; (void)hipGetLastError(); }
     }
     return PDLP_OK;

@@ -74,6 +74,13 @@ class Comm:
         else:
             self.dist.all_reduce(t, op=op, group=self.group)
 
+    def all_reduce_sum_async(self, t: torch.Tensor):
+        """the same reduction, not waited for: returns a handle whose ``wait()`` makes the current stream wait (None: already done)"""
+        if self.backend == "gloo" and t.is_cuda:
+            self.all_reduce_sum(t)
+            return None
+        return self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def all_reduce_max(self, t: torch.Tensor):
         self.all_reduce_sum(t, self.dist.ReduceOp.MAX)
 
@@ -150,6 +157,9 @@ class PdlpEngine:
             self.set_option(N.OPT_RUNNING_KKT, 0)
         if os.environ.get("PDLP_NO_KTY_REUSE") is not None:
             self.set_option(N.OPT_KTY_REUSE, 0)
+        self.producer_pieces = os.environ.get("PDLP_PRODUCER_PIECES", "1")[:1] != "0"
+        if os.environ.get("PDLP_PRODUCER_PIECES", "1") != "1":
+            self.set_option(N.OPT_PRODUCER_PIECES, int(os.environ["PDLP_PRODUCER_PIECES"]))
         if os.environ.get("PDLP_GRAPH") is not None and self.comm is None:
             self.set_option(N.OPT_GRAPH, 1)
         self.exact = None
@@ -171,6 +181,12 @@ class PdlpEngine:
         self.lib_comm, self.lib_comm_log = False, []
         if self.comm is not None and self.comm.backend == "nccl" and tiles and os.environ.get("PDLP_LIB_COMM", "0") == "1":
             self.enable_library_comm()
+
+    def set_producer_pieces(self, on: bool):
+        """results of split products leave piece by piece with a chunked exchange (default) or only when the half-step has finished
+        (round-4 behaviour; A/B timing and tests).  Every rank must choose the same."""
+        self.set_option(N.OPT_PRODUCER_PIECES, int(bool(on)))
+        self.producer_pieces = bool(on)
 
     def set_option(self, option: int, value: int):
         """``pdlp_set_option``: the handle's test / tool switches (``N.OPT_*``)"""
@@ -518,14 +534,33 @@ class PdlpEngine:
             plan = self._plans[int(transpose)] = [(int(b[c]), int(b[c + 1])) for c in range(nc.value)]
         return plan
 
-    def _exchange(self, transpose: int, full: torch.Tensor):
+    def _half_in_pieces(self, dual: bool, a: int, full: torch.Tensor):
+        """One half-step.  If the exchange that follows it is chunked its result leaves in the pieces of that plan: the rows of
+        piece c (``pdlp_*_half_piece``), then piece c's all-gather -- issued behind those rows, it runs while piece c + 1's rows
+        are multiplied.  Returns the pieces' handles, or None when the half-step went out whole (the caller exchanges afterwards).
+        Every rank takes the same branch: the plan is a function of the block length and the piece count alone."""
+        plan = self.exchange_plan(1 if dual else 0)        # the plan of the exchange that FOLLOWS: y after the dual, xbar after the primal
+        lib, h = self.lib, self.h
+        if len(plan) == 1 or not self.producer_pieces:
+            N.check((lib.pdlp_dual_half if dual else lib.pdlp_primal_half)(h, a), "pdlp_dual_half" if dual else "pdlp_primal_half")
+            return None
+        piece = lib.pdlp_dual_half_piece if dual else lib.pdlp_primal_half_piece
+        works = []
+        for c, (lo, hi) in enumerate(plan):
+            N.check(piece(h, a, c, len(plan)), "pdlp_dual_half_piece" if dual else "pdlp_primal_half_piece")
+            works.append(self.comm.all_gather_piece(full, lo, hi))
+        return works
+
+    def _exchange(self, transpose: int, full: torch.Tensor, works=None):
         """the input of the next product to every rank, in the pieces of its plan; the panels a piece completes are multiplied as
-        soon as it is there (all but the last piece's: those belong to the half-step that follows)"""
+        soon as it is there (all but the last piece's: those belong to the half-step that follows).  ``works``: the pieces are
+        on their way already (``_half_in_pieces``)"""
         plan = self.exchange_plan(transpose)
-        if len(plan) == 1:
+        if works is None and len(plan) == 1:
             self.comm.all_gather(full)
             return
-        works = [self.comm.all_gather_piece(full, lo, hi) for lo, hi in plan]
+        if works is None:
+            works = [self.comm.all_gather_piece(full, lo, hi) for lo, hi in plan]
         for c, w in enumerate(works):
             if w is not None:
                 w.wait()
@@ -628,19 +663,30 @@ class PdlpEngine:
         if self.delta and iters > 0 and not self.delta_state()["anchors_valid"]:
             self.refresh_products()
         for it in range(iters):
-            N.check(lib.pdlp_primal_half(h, a), "pdlp_primal_half")
+            # With a chunked exchange the result of a half-step leaves piece by piece (_half_in_pieces): piece c's all-gather is
+            # issued behind the rows it is made of and runs while the rows of piece c + 1 are still being multiplied.
+            wx = self._half_in_pieces(False, a, xbar)
             # the panels of K that meet this rank's own block of xbar are multiplied (side stream) while the
             # other blocks are still on the wire; the same for K' and y below
             N.check(lib.pdlp_dual_half_begin(h, a), "pdlp_dual_half_begin")
-            self._exchange(0, xbar)                        # K xbar needs every rank's block of xbar
-            N.check(lib.pdlp_dual_half(h, a), "pdlp_dual_half")
-            ynew = gdy if self.delta else self.buffer(N.BUF_Y_CUR)      # the next K'y needs every rank's block of y (buffers alternate)
+            self._exchange(0, xbar, wx)                    # K xbar needs every rank's block of xbar
+            ynew = gdy if self.delta else self.buffer(N.BUF_Y_PREV)     # where the dual half-step writes (the buffers alternate)
+            wy = self._half_in_pieces(True, a, ynew)
+            ar = None
+            if adaptive and wy is not None:
+                # the step-size rule's three sums queue up behind the pieces of y and are reduced while the panels those pieces
+                # complete are multiplied (same sums: only the order in which independent work is issued differs)
+                N.check(lib.pdlp_adaptive_reduce(h), "pdlp_adaptive_reduce")
+                ar = comm.all_reduce_sum_async(red)
             if it + 1 < iters:                             # (the new y is final: a rejected adaptive step is kept, quirk Q1)
                 N.check(lib.pdlp_primal_half_begin(h), "pdlp_primal_half_begin")
-            self._exchange(1, ynew)                        # (no product under way after the last iteration: the pieces just arrive)
+            self._exchange(1, ynew, wy)                    # (no product under way after the last iteration: the pieces just arrive)
             if adaptive:
-                N.check(lib.pdlp_adaptive_reduce(h), "pdlp_adaptive_reduce")
-                comm.all_reduce_sum(red)
+                if wy is None:
+                    N.check(lib.pdlp_adaptive_reduce(h), "pdlp_adaptive_reduce")
+                    comm.all_reduce_sum(red)
+                elif ar is not None:
+                    ar.wait()
                 N.check(lib.pdlp_adaptive_update(h), "pdlp_adaptive_update")
         if not adaptive and iters > 0:
             N.check(self.lib.pdlp_fixed_advance(self.h, int(iters)), "pdlp_fixed_advance")
