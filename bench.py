@@ -623,6 +623,7 @@ def main(argv=None):
         else:
             eng.set_exchange_chunks(int(args.exchange_chunks))
             exchange["pieces"] = {"chunks": int(args.exchange_chunks)}
+        exchange["pieces"]["producer_pieces"] = bool(eng.producer_pieces and eng.xchunks > 1)
 
     def fence():
         if comm is not None:
@@ -721,11 +722,10 @@ def main(argv=None):
         except Exception as e:
             out["timing"]["phases"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         deadman.disarm()
-        if args.lib_comm == "auto" and comm.backend == "nccl" and eng.xchunks > 1:
-            # (a chunked exchange stays on torch.distributed's own collectives here: the library's form of it -- grouped broadcasts
-            # on a second stream -- has only ever run against the test stand-in, and a first contact belongs outside a benchmark)
-            exchange["path"] = "torch.distributed loop (chunked exchange: library driver not tried)"
-        elif args.lib_comm == "auto" and comm.backend == "nccl":
+        if args.lib_comm == "auto" and comm.backend == "nccl":
+            # (chunked exchanges too since round 5: the library's form of them -- grouped in-place broadcasts on its communication
+            # stream, the pieces behind the rows they are made of -- runs on real RCCL in tests/test_distributed.py::
+            # test_rccl_world1_library_communicator; the cross-check below compares it bit for bit with the torch loop first)
             library_phase(out, exchange, eng, args.steps, timed_region, norm_elapsed, rank,
                           limit=float(os.environ.get("PDLP_COMM_TIMEOUT", "90")), first_region_s=first_region_s)
     # from here on (time to tolerance, teardown of the communicators) a hang must not cost the line either

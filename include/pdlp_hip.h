@@ -189,6 +189,13 @@ int pdlp_split_info(pdlp_handle h, int transpose, int32_t out[4]);
  * most row blocks (slots of per-workgroup partial sums), most rows per thread, most items per tile, threads per workgroup of the
  * tiled kernel (a row block is that many times rpt rows), 0 (reserved)} */
 int pdlp_tile_limits(pdlp_handle h, int32_t out[6]);
+/* The INTENDED loop of the adaptive step (SURVEY quirk Q1's optional flag; the live package takes ONE trial and keeps a rejected step,
+ * /root/reference/PDLP/primal_dual_hybrid_gradient_step.py:71,110-115 -- the loop it was meant to be is
+ * /root/reference/enhancements/test_ass.py:322-363): after an adaptive iteration whose trial was REJECTED (scalar "accepted" = 0)
+ * this discards the trial -- the old (x, y) is current again, its weight leaves the average, k goes back, the step size stays the
+ * shrunk eta' -- so that the iteration can be issued again.  Off the default path (pdlp_algorithm(adaptive_retry=True)); float32 and
+ * float64 handles; K x of the old x is recomputed by the next half-step and the running products of the period are dropped. */
+int pdlp_adaptive_retry(pdlp_handle h);
 /* adaptive rule, part 1: reduce this rank's ||dx||^2, ||dy||^2, dy'K dx into PDLP_BUF_RED[0..2]
  * (all-reduce them across ranks before part 2) -- step.py:91-96 */
 int pdlp_adaptive_reduce(pdlp_handle h);
@@ -349,6 +356,18 @@ int pdlp_mv_combine(int dtype, int64_t rows, int j, const void* V, const void* W
 int pdlp_spmv(pdlp_handle h, int transpose, const void* in_full, void* out_local);
 /* spectral_norm_estimate_torch helpers.py:41-51 with the start vector given (single rank) */
 int pdlp_power_iteration(pdlp_handle h, const void* b0, int iters, void* work_n, void* work_m, double* sigma);
+
+/* ---- tracing: roctx ranges for rocprofv3 --marker-trace ------------------------------------------ */
+/* The reference times its sections with a wall-clock Timer (PDLP/util.py:6-27).  Here the phases of a solve are roctx ranges:
+ * inside the library around pdlp_iterate ("pdlp: N adaptive iterations"), every KKT pass, the exact product refresh, the power
+ * iteration and the pieces of a chunked exchange; the host layer adds "restart check", "restart work", "Ruiz sweep", "tile build"
+ * with pdlp_range_push / pdlp_range_pop.  level 0: off (default: no library is loaded, no call is made); 1: ranges on the host
+ * timeline; 2: the stream is synchronised at both ends of a range, so a range's duration is the GPU time of its work (the
+ * per-phase table of profiles/README.md).  The roctx library is resolved with dlopen (librocprofiler-sdk-roctx.so, else
+ * libroctx64.so); PDLP_ERR_STATE when there is none. */
+int pdlp_trace_enable(int level);
+int pdlp_range_push(const char* name, void* stream);
+int pdlp_range_pop(void* stream);
 
 /* Measurement aid (no counterpart in the reference): GB/s at which this GPU streams `bytes` (>= 16 MiB, 16-byte aligned, zero
  * filled) with the tiled kernel's access pattern -- 512 workgroups, each its own contiguous slice, four 16-byte non-temporal loads

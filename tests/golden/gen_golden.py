@@ -551,8 +551,58 @@ def g13_forced_trace_more(cases):
                      "forced_trace_more.npz")
 
 
+def g14_adaptive_retry(cases):
+    """round 5 (SURVEY quirk Q1's optional flag): the INTENDED adaptive step -- retry from the saved (x, y) with the shrunk step size
+    until a trial is accepted -- as the reference's own experiment runs it: ``pdhg_torch`` of /root/reference/enhancements/test_ass.py
+    (:313-363), imported here.  Its step-size estimate is pinned (the exact spectral norm times ``scale``: < 1 makes the first step
+    sizes too large, so trials are rejected) and its prints are captured: one three-value print per trial, "eta set" on acceptance.
+    Recorded: the trial count and the step size after every iteration, and x after 1, 3, 12 and 40 iterations."""
+    import contextlib
+    import importlib.util
+    import io
+    spec = importlib.util.spec_from_file_location("ref_test_ass", "/root/reference/enhancements/test_ass.py")
+    ta = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ta)
+    out = {}
+    for name in ("mixed_27x32", "mixed_400x300", "box_200x150"):
+        lp = cases[name]
+        K = csr_to_dense(lp)
+        sig = float(torch.linalg.matrix_norm(K.double(), 2))
+        is_neg_inf, is_pos_inf, l_dual, u_dual = masks(col(lp.l), col(lp.u))
+        put(out, name, lp_arrays(lp))
+        G, A = K[:lp.m_ineq], K[lp.m_ineq:]
+        h, b = col(lp.q[:lp.m_ineq]), col(lp.q[lp.m_ineq:])
+        for tag, scale in (("tight", 1.0), ("loose", 0.04)):
+            ta.spectral_norm_estimate_torch = lambda A_, num_iters=10, v=sig * scale: torch.tensor(v, dtype=torch.float32)
+            log = []
+            ta.print = lambda *a, **k: log.append(a)
+            rec = {}
+            for iters in (1, 3, 12, 40):
+                log.clear()
+                with contextlib.redirect_stdout(io.StringIO()):
+                    x, obj, k = ta.pdhg_torch(col(lp.c), G, h, A, b, col(lp.l), col(lp.u), is_neg_inf, is_pos_inf, l_dual, u_dual, "cpu",
+                                              max_iter=iters, tol=0.0, verbose=False)
+                assert k == iters
+                rec[f"x{iters}"] = x.flatten().numpy().copy()
+                rec[f"obj{iters}"] = np.float64(obj)
+            trials, etas, cur = [], [], 0
+            for a in log:                          # (the log of the 40-iteration run)
+                if len(a) == 3:
+                    cur += 1
+                elif len(a) == 2 and a[0] == "eta set":
+                    trials.append(cur)
+                    etas.append(float(a[1]))
+                    cur = 0
+            assert len(trials) == 40, (name, tag, len(trials))
+            rec.update(trials=np.asarray(trials, np.int32), eta_after=np.asarray(etas, np.float64),
+                       eta0=np.float32(0.9) / np.float32(sig * scale),
+                       omega=(torch.linalg.norm(lp.c) / torch.linalg.norm(lp.q)).to(torch.float32).numpy())
+            put(out, f"{name}/{tag}", rec)
+    np.savez_compressed(os.path.join(OUT, "adaptive_retry.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"}
+    which = set(sys.argv[1:]) or {"g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"}
     cases = lp_cases()
     if "g1" in which: g1_step_fixed(cases)
     if "g2" in which: g2_step_adaptive(cases)
@@ -567,5 +617,6 @@ if __name__ == "__main__":
     if "g11" in which: g11_fishnet(cases)
     if "g12" in which: g12_forced_trace(cases)
     if "g13" in which: g13_forced_trace_more(cases)
+    if "g14" in which: g14_adaptive_retry(cases)
     print("golden fixtures written to", OUT)
 

@@ -1754,3 +1754,65 @@ def test_column_sorted_row_blocks_match_csr_order(monkeypatch, precision):
         outs.append((x, y, e.kkt(N.CUR, 1.0)["kkt"]))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
 
+
+
+@pytest.mark.parametrize("family", ["csr", "tiled"])
+@pytest.mark.parametrize("name", ["mixed_27x32", "mixed_400x300", "box_200x150"])
+@pytest.mark.parametrize("tag", ["tight", "loose"])
+def test_adaptive_retry_vs_the_references_experiment(golden, name, tag, family):
+    """SURVEY quirk Q1's optional flag: with ``adaptive_retry`` a rejected trial of the adaptive step is
+    discarded (``pdlp_adaptive_retry``) and issued again with the shrunk step size until one is accepted -- the loop of
+    /root/reference/enhancements/test_ass.py:322-363.  Against recorded runs of that script's ``pdhg_torch`` (40 iterations from
+    zero, "loose": first step sizes 25 times too large): the same number of trials in every iteration, the same step sizes, the same
+    x after 1, 3, 12 and 40 iterations; and the oracle's restatement of the loop step for step.  The default (one trial, a
+    rejected step is kept) is untouched: its tests are the ones above."""
+    g = golden("adaptive_retry.npz")
+    a, K, o, eng = golden_lp(g, name, family=family)
+    r = g.group(f"{name}/{tag}")
+    omega = float(r["omega"])
+    eng.set_iterate(torch.zeros(int(a["n"]), device=DEV), torch.zeros(int(a["m"]), device=DEV))
+    eng.set_step(float(r["eta0"]), omega, 1.0, 0)
+    xo, yo, eo = np.zeros(int(a["n"]), np.float32), np.zeros(int(a["m"]), np.float32), np.float32(r["eta0"])
+    trials = []
+    for k in range(1, 41):
+        t = 0
+        while True:
+            eng.iterate(1, True)
+            t += 1
+            sc = eng.scalars()
+            if sc["accepted"] or t >= 200:
+                break
+            eng.adaptive_retry()
+            sc2 = eng.scalars()
+            assert sc2["k"] == k - 1 and sc2["w_pending"] == 0.0 and sc2["eta"] == sc["eta"]      # the trial is gone, eta' stays
+        trials.append(t)
+        assert sc["k"] == k
+        # (eta_bar is a ratio whose denominator 2 dy'K dx cancels: float32 summation order shows in the 4th digit after a few steps)
+        np.testing.assert_allclose(sc["eta"], r["eta_after"][k - 1], rtol=2e-3)
+        xo, yo, eo, to = o.step_adaptive_retry(xo, yo, eo, np.float32(omega), 1.0, k)
+        if k in (1, 3, 12, 40):
+            x, y = eng.get_iterate(N.CUR)
+            tol = 2e-5 if k == 1 else 1e-3
+            close(x, r[f"x{k}"], tol)
+            close(x, xo, tol)
+            close(y, yo, tol)
+    assert trials == r["trials"].tolist() and max(trials) >= 2
+    # the weights of the average: one per iteration -- a rejected trial's weight left eta_total again (float32 sum of 40 step sizes)
+    etas_used = np.concatenate([[np.float32(r["eta0"])], r["eta_after"][:-1].astype(np.float32)])
+    # (an accepted trial weighs with the step size it was taken with: eta0 for iteration 1 only if its first trial was accepted)
+    assert 0.2 * float(etas_used.sum()) <= eng.scalars()["eta_sum"] <= 1.0001 * float(etas_used.sum())
+
+def test_adaptive_retry_whole_solve(golden):
+    """pdlp_algorithm(adaptive_retry=True): a whole restarted solve with the retry loop reaches the optimum, counts one KKT pass per
+    trial (j >= k + ...) and differs from the single-trial run only where trials were rejected"""
+    g = golden("solve_trace.npz")
+    a, K, o, _ = golden_lp(g, "mixed_400x300")
+    r = g.group("mixed_400x300/adaptive_pw")
+    args = (K, int(a["m_ineq"]), dev(a["c"]), dev(a["q"]), dev(a["l"]), dev(a["u"]), DEV)
+    one = tp.pdlp_algorithm(*args, tol=1e-4, verbose=False, primal_update=True, adaptive=True, b0=dev(r["b0"]))
+    many = tp.pdlp_algorithm(*args, tol=1e-4, verbose=False, primal_update=True, adaptive=True, b0=dev(r["b0"]), adaptive_retry=True)
+    assert one[5] == many[5] == "Solved"
+    assert abs(one[1] - many[1]) <= 2e-3 * (1 + abs(one[1]))
+    assert many[4] >= many[2]                      # one pass per trial, at least one trial per iteration
+    with pytest.raises(ValueError):
+        tp.pdlp_algorithm(*args, tol=1e-4, verbose=False, adaptive=True, adaptive_retry=True, precision="mixed")

@@ -61,6 +61,27 @@ def test_step_adaptive(golden, name, tag):
     assert r["j_out"] == r["j_in"] + 1          # one KKT pass per call (quirk Q1)
 
 
+@pytest.mark.parametrize("name", ["mixed_27x32", "mixed_400x300", "box_200x150"])
+@pytest.mark.parametrize("tag", ["tight", "loose"])
+def test_step_adaptive_retry_vs_the_references_experiment(golden, name, tag):
+    """SURVEY quirk Q1's optional flag: the intended loop -- retry with the shrunk step size until a trial is accepted -- against
+    recorded runs of the reference's own experiment (enhancements/test_ass.py: pdhg_torch, imported by the generator): the same
+    number of trials in every one of 40 iterations ("loose": first step sizes 25 times too large, so trials ARE rejected), the
+    same step sizes, the same x after 1, 3, 12 and 40 iterations"""
+    g = golden("adaptive_retry.npz")
+    lp = lp_from(g, name)
+    r = g.group(f"{name}/{tag}")
+    x, y = np.zeros(lp.n, np.float32), np.zeros(lp.m, np.float32)
+    eta, trials = np.float32(r["eta0"]), []
+    for k in range(1, 41):
+        x, y, eta, t = lp.step_adaptive_retry(x, y, eta, np.float32(r["omega"]), 1.0, k)
+        trials.append(t)
+        np.testing.assert_allclose(eta, r["eta_after"][k - 1], rtol=5e-5 * k)
+        if k in (1, 3, 12, 40):
+            close(x, r[f"x{k}"], 3e-6 * k)
+    assert trials == r["trials"].tolist() and max(trials) >= 2
+
+
 @pytest.mark.parametrize("name", LP_CASES)
 def test_step_adaptive_chain(golden, name):
     g = golden("step_adaptive.npz")

@@ -29,6 +29,10 @@ def parse_args(argv=None):
     p.add_argument("--precondition", action="store_true")
     p.add_argument("--primal_weight_update", action="store_true")
     p.add_argument("--adaptive_stepsize", action="store_true")
+    p.add_argument("--adaptive_retry", action="store_true",
+                   help="with --adaptive_stepsize: repeat a rejected step with the shrunk step size until one is accepted (the loop "
+                        "the reference's adaptive step was meant to be, enhancements/test_ass.py:322-363); default: one trial, as the "
+                        "live package does")
     p.add_argument("--infeasibility_detect", action="store_true")
     p.add_argument("--verbose", action="store_true")
     p.add_argument("--support_sparse", action="store_true", help="accepted; matrices are always sparse here")
@@ -109,7 +113,7 @@ def main(argv=None) -> int:
             continue
         try:
             r = solve_lp(problem, tol=args.tolerance, precondition=args.precondition, primal_weight_update=args.primal_weight_update,
-                         adaptive_stepsize=args.adaptive_stepsize, max_kkt=args.max_kkt, time_limit=args.time_limit,
+                         adaptive_stepsize=args.adaptive_stepsize, adaptive_retry=args.adaptive_retry, max_kkt=args.max_kkt, time_limit=args.time_limit,
                          verbose=args.verbose, dtype=dtype, seed=args.seed, fishnet=args.fishnet, comm=comm,
                          infeasibility_detect=args.infeasibility_detect, precision="mixed" if args.dtype == "mixed" else None)
             print(f"Solver uses {r.time:.4f} seconds.\nStatus: {r.status}")

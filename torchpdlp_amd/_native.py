@@ -19,7 +19,7 @@ CUR, AVG, PREV = 0, 1, 2
 NRED, NSCAL = 8, 16
 OPT_RUNNING_KKT, OPT_KTY_REUSE, OPT_GRAPH, OPT_SPLIT_SLOTS, OPT_PRODUCER_PIECES = range(5)
 # indices into the scalar block
-S_ETA, S_OMEGA, S_THETA, S_TAU, S_SIGMA, S_WPEND, S_ETASUM, S_K, S_INV1PT, S_ACCEPT, S_ETABAR, S_DEN = range(12)
+S_ETA, S_OMEGA, S_THETA, S_TAU, S_SIGMA, S_WPEND, S_ETASUM, S_K, S_INV1PT, S_ACCEPT, S_ETABAR, S_DEN, S_ETASUM_PREV = range(13)
 
 
 class PdlpProblem(C.Structure):
@@ -67,6 +67,7 @@ SIGNATURES = {
     "pdlp_dual_half_begin": (_I, [_H, _I]),
     "pdlp_split_info": (_I, [_H, _I, C.POINTER(C.c_int32)]),
     "pdlp_tile_limits": (_I, [_H, C.POINTER(C.c_int32)]),
+    "pdlp_adaptive_retry": (_I, [_H]),
     "pdlp_adaptive_reduce": (_I, [_H]),
     "pdlp_adaptive_update": (_I, [_H]),
     "pdlp_iterate": (_I, [_H, _I, _I]),
@@ -103,6 +104,9 @@ SIGNATURES = {
     "pdlp_spmv": (_I, [_H, _I, _P, _P]),
     "pdlp_power_iteration": (_I, [_H, _P, _I, _P, _P, C.POINTER(_D)]),
     "pdlp_probe_stream_read": (_I, [_P, _I64, _I, _P, C.POINTER(_D)]),
+    "pdlp_trace_enable": (_I, [_I]),
+    "pdlp_range_push": (_I, [C.c_char_p, _P]),
+    "pdlp_range_pop": (_I, [_P]),
     "pdlp_probe_gather": (_I, [_P, _I64, _I64, _I, _P, C.POINTER(_D)]),
     "pdlp_csr_row_scale_factors": (_I, [_I, _I64, _P, _P, _D, _P, _P]),
     "pdlp_csr_div_rows": (_I, [_I, _I64, _P, _P, _P, _P]),
@@ -137,6 +141,33 @@ def load():
         raise PdlpError(f"libpdlp_hip.so ABI {lib.pdlp_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
     _lib = lib
     return lib
+
+
+class trace_range:
+    """``with trace_range("restart check", stream):`` -- a roctx range (rocprofv3 --marker-trace) when tracing is on
+    (``PDLP_ROCTX=1|2`` in the environment, or ``pdlp_trace_enable``); nothing otherwise.  ``stream``: a torch stream or None."""
+    level = None
+
+    def __init__(self, name: str, stream=None):
+        self.name, self.stream = name.encode(), (None if stream is None else stream.cuda_stream)
+
+    @classmethod
+    def enabled(cls) -> bool:
+        if cls.level is None:
+            lvl = int(os.environ.get("PDLP_ROCTX", "0") or 0)
+            cls.level = lvl if lvl > 0 and load().pdlp_trace_enable(lvl) == 0 else 0
+        return cls.level > 0
+
+    def __enter__(self):
+        self.on = self.enabled()
+        if self.on:
+            load().pdlp_range_push(self.name, self.stream)
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            load().pdlp_range_pop(self.stream)
+        return False
 
 
 def check(rc: int, what: str = ""):

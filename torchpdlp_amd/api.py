@@ -36,11 +36,11 @@ def solve_lp(problem: Union[str, os.PathLike, tuple], device=None, tol: float = 
              time_limit: float = 3600, verbose: bool = False, restart_period: int = 40, dtype=torch.float32,
              seed: Optional[int] = None, compat: bool = True, x_init=None, y_init=None, trace=None,
              fishnet: bool = False, comm=None, infeasibility_detect: bool = False, infeas_tol: float = 1e-4,
-             precision: Optional[str] = None) -> LPResult:
+             precision: Optional[str] = None, adaptive_retry: bool = False) -> LPResult:
     """Solve ``min c'x, K[:m_ineq]x >= q[:m_ineq], K[m_ineq:]x = q[m_ineq:], l <= x <= u`` on the current HIP device.
 
     ``problem`` is an MPS path or ``(c, K, q, m_ineq, l, u)`` with ``K`` dense / COO / scipy-sparse / ``CsrPair``.
-    Flags carry the reference CLI's names (main.py:11-39).  ``dtype=torch.float64`` is the mode for tolerances
+    Flags carry the reference CLI's names (main.py:11-39); ``adaptive_retry`` (not in the reference's CLI) is ``pdlp_algorithm``'s.  ``dtype=torch.float64`` is the mode for tolerances
     below float32 resolution (the reference is float32 only); ``precision="mixed"`` (the problem is then read in float64) is the
     fast way there: float32 matrix entries under float64 vectors, iterations on the float32 kernels (``pdlp_algorithm``).
     ``infeasibility_detect`` runs the reference's detector
@@ -59,7 +59,7 @@ def solve_lp(problem: Union[str, os.PathLike, tuple], device=None, tol: float = 
         if cm.world > 1:
             return _solve_lp_sharded(problem, cm, device, tol, precondition, primal_weight_update, adaptive_stepsize, max_kkt, time_limit,
                                      verbose, restart_period, dtype, seed, compat, x_init, y_init, trace, infeasibility_detect,
-                                     infeas_tol, precision)
+                                     infeas_tol, precision, adaptive_retry)
     if isinstance(problem, (str, os.PathLike)):
         c, K, q, m_ineq, l, u = mps_to_standard_form(os.fspath(problem), device=device, verbose=verbose, compat=compat, dtype=dtype)
     else:
@@ -80,14 +80,16 @@ def solve_lp(problem: Union[str, os.PathLike, tuple], device=None, tol: float = 
         Ks, m_ineq, cs, qs, ls, us, device, max_kkt=max_kkt, tol=tol, verbose=verbose, restart_period=restart_period,
         precondition=precondition, primal_update=primal_weight_update, adaptive=adaptive_stepsize,
         data_precond=data_precond, time_limit=time_limit, time_used=time_used, x_init=x_init, y_init=y_init, seed=seed,
-        trace=trace, comm=comm, infeasibility_detect=infeasibility_detect, infeas_tol=infeas_tol, precision=precision)
+        trace=trace, comm=comm, infeasibility_detect=infeasibility_detect, infeas_tol=infeas_tol, precision=precision,
+        adaptive_retry=adaptive_retry)
     if precondition:        # the reference returns the scaled iterate (quirk Q4); solve_lp un-scales: x = D_col x_s (pdhg.py:161)
         x = data_precond[0].view(-1, 1).to(x.dtype) * x
     return LPResult(x, obj, k, n, j, status, total)
 
 
 def _solve_lp_sharded(problem, comm, device, tol, precondition, primal_weight_update, adaptive_stepsize, max_kkt, time_limit, verbose,
-                      restart_period, dtype, seed, compat, x_init, y_init, trace, infeasibility_detect, infeas_tol, precision) -> LPResult:
+                      restart_period, dtype, seed, compat, x_init, y_init, trace, infeasibility_detect, infeas_tol, precision,
+                      adaptive_retry=False) -> LPResult:
     """``solve_lp`` over the ranks of ``comm``: the problem is read (or taken) on the host by every rank, cut into blocks balanced
     by non-zeros, and only this rank's blocks go to its GPU; Ruiz (enhancements.py:4-71) runs on the shards, the solve is
     ``run_pdlp`` on the sharded engine (pdhg.py:7-181), and every rank returns the full un-scaled solution."""
@@ -116,7 +118,7 @@ def _solve_lp_sharded(problem, comm, device, tol, precondition, primal_weight_up
     x, obj, k, nr, j, status, total = run_pdlp(eng, max_kkt, tol, verbose and comm.rank == 0, restart_period, precondition,
                                                primal_weight_update, adaptive_stepsize, time_limit, time_used, x_init, y_init,
                                                seed=0 if seed is None else seed, trace=trace,
-                                               infeasibility_detect=infeasibility_detect, infeas_tol=infeas_tol)
+                                               infeasibility_detect=infeasibility_detect, infeas_tol=infeas_tol, adaptive_retry=adaptive_retry)
     if precondition:
         x = x * eng.d_col
     return LPResult(gather_solution(eng, x, n).view(-1, 1), obj, k, nr, j, status, total)

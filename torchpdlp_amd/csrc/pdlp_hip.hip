@@ -39,7 +39,7 @@ constexpr int MAX_CHUNKS = 4;    // chunks of the exchange of a gathered vector 
 constexpr int MAX_PHASE = MAX_CHUNKS + 2;
 
 // indices into the device scalar block (double[PDLP_NSCAL])
-enum { S_ETA = 0, S_OMEGA, S_THETA, S_TAU, S_SIGMA, S_WPEND, S_ETASUM, S_K, S_INV1PT, S_ACCEPT, S_ETABAR, S_DEN };
+enum { S_ETA = 0, S_OMEGA, S_THETA, S_TAU, S_SIGMA, S_WPEND, S_ETASUM, S_K, S_INV1PT, S_ACCEPT, S_ETABAR, S_DEN, S_ETASUM_PREV };
 
 #define HIP_TRY(expr)                                                   \
     do {                                                                \
@@ -147,6 +147,53 @@ int rccl_load(const char* path)
         ncclResult_t r_ = (expr);                            \
         if (r_ != ncclSuccess) { g_rccl.last_error = (int)r_; return PDLP_ERR_COMM; } \
     } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// roctx ranges (rocprofv3 --marker-trace): the counterpart of the reference's Timer (PDLP/util.py:6-27, wall-clock sections printed at
+// the end of a run).  Resolved with dlopen on first use after pdlp_trace_enable -- no link-time dependency, nothing happens when
+// tracing is off.  Level 2 also synchronises the given stream at both ends of a range, so that the range's wall time IS the
+// GPU time of what was enqueued inside it (the per-phase table of profiles/README.md); level 1 marks the host side only.
+// ------------------------------------------------------------------------------------------------
+struct Roctx {
+    int level = 0;
+    bool tried = false;
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+};
+Roctx g_roctx;
+
+void roctx_load()
+{
+    if (g_roctx.tried) return;
+    g_roctx.tried = true;
+    const char* names[] = {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "/opt/rocm/lib/librocprofiler-sdk-roctx.so",
+                           "libroctx64.so", "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so"};
+    for (const char* nm : names) {
+        void* lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) continue;
+        g_roctx.push = (int (*)(const char*))dlsym(lib, "roctxRangePushA");
+        g_roctx.pop = (int (*)())dlsym(lib, "roctxRangePop");
+        if (g_roctx.push && g_roctx.pop) return;
+        g_roctx.push = nullptr; g_roctx.pop = nullptr;
+    }
+}
+
+struct Range {         // scoped range on the handle's stream
+    hipStream_t s;
+    bool on;
+    Range(const char* name, hipStream_t stream) : s(stream), on(g_roctx.level > 0 && g_roctx.push)
+    {
+        if (!on) return;
+        if (g_roctx.level > 1) (void)hipStreamSynchronize(s);
+        (void)g_roctx.push(name);
+    }
+    ~Range()
+    {
+        if (!on) return;
+        if (g_roctx.level > 1) (void)hipStreamSynchronize(s);
+        (void)g_roctx.pop();
+    }
+};
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -1266,7 +1313,7 @@ int read_last_rowptr(const int64_t* rp, int64_t rows, int64_t* nnz, hipStream_t 
 // ================================================================================================
 extern "C" {
 
-int pdlp_abi_version(void) { return 16; }  // 16: pdlp_set_option (the library reads no environment variables), pdlp_mv_product, pdlp_mv_combine, pdlp_vec_sqdist, pdlp_probe_gather, pdlp_tile_limits reports the threads per workgroup, pdlp_primal_half_piece / pdlp_dual_half_piece (results of split products leave piece by piece); 15: 64-bit row pointers, row-block bases of the tiles and schedule offsets (more than 2^31 non-zeros per handle); 14: pdlp_probe_stream_read; 13: chunked exchange (pdlp_set_exchange_chunks, pdlp_exchange_plan, pdlp_half_chunk); 12: count words of a tile laid out for coalesced loads; 11: pdlp_comm_load; 10: pdlp_set_anchors; 9: pdlp_attach_sorted; 8: running products, pdlp_flush_average(h, adaptive); 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
+int pdlp_abi_version(void) { return 16; }  // 16: pdlp_set_option (the library reads no environment variables), pdlp_mv_product, pdlp_mv_combine, pdlp_vec_sqdist, pdlp_probe_gather, pdlp_tile_limits reports the threads per workgroup, pdlp_primal_half_piece / pdlp_dual_half_piece (results of split products leave piece by piece), pdlp_trace_enable / pdlp_range_push / pdlp_range_pop (roctx), pdlp_adaptive_retry; 15: 64-bit row pointers, row-block bases of the tiles and schedule offsets (more than 2^31 non-zeros per handle); 14: pdlp_probe_stream_read; 13: chunked exchange (pdlp_set_exchange_chunks, pdlp_exchange_plan, pdlp_half_chunk); 12: count words of a tile laid out for coalesced loads; 11: pdlp_comm_load; 10: pdlp_set_anchors; 9: pdlp_attach_sorted; 8: running products, pdlp_flush_average(h, adaptive); 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
 
 const char* pdlp_strerror(int code)
 {
@@ -1689,6 +1736,27 @@ int pdlp_tile_limits(pdlp_handle h, int32_t out[6])
     return PDLP_OK;
 }
 
+int pdlp_adaptive_retry(pdlp_handle h)
+{
+    if (!h) return PDLP_ERR_INVALID;
+    if (h->delta || h->sK.pending || h->sKT.pending || h->graph_ok) return PDLP_ERR_STATE;   // (float32 / float64 handles, between iterations)
+    // the scalars: the rejected trial's weight leaves eta_total again, nothing is pending (the trial's epilogues have folded the
+    // previous iterate's weight into the sums: the repeated half-steps must add nothing), k goes back; eta keeps the rule's eta'
+    hipLaunchKernelGGL(k_retry_scalars, dim3(1), dim3(1), 0, h->stream, h->sc);
+    HIP_TRY(hipGetLastError());
+    // the iterate: the trial wrote x+, y+ into the "previous" buffers and made them current; the old (x, y) is intact in what is now
+    // the previous pair
+    const int t = h->ix_cur;
+    h->ix_cur = h->ix_prev;
+    h->ix_prev = t;
+    if (h->since_reset > 0) --h->since_reset;
+    h->kx_valid = false;              // the carried K x now belongs to the rejected x+: recomputed by the next dual half-step
+    h->sums_broken = true;            // (the running products of this period saw the rejected trial: the checks multiply instead)
+    h->cand_valid[0] = h->cand_valid[1] = false;
+    h->kty_cur = -1; h->kty_tail_done = false; h->avg_products = false;
+    return PDLP_OK;
+}
+
 int pdlp_adaptive_reduce(pdlp_handle h)
 {
     if (!h) return PDLP_ERR_INVALID;
@@ -1804,6 +1872,8 @@ int comm_all_gather(pdlp_handle h, void* full, int64_t count, bool f32)
 int comm_exchange_piece(pdlp_handle h, int c, const int64_t* sb, void* full, int64_t block, bool f32, hipEvent_t ready)
 {
     const size_t esz = f32 ? 4 : 8;
+    if (g_roctx.level > 0 && g_roctx.push) (void)g_roctx.push("pdlp: exchange piece (grouped broadcasts issued)");
+    struct Pop { ~Pop() { if (g_roctx.level > 0 && g_roctx.pop) (void)g_roctx.pop(); } } pop_;
     HIP_TRY(hipStreamWaitEvent(h->cstream, ready, 0));          // this rank's part of the piece is final
     const int64_t lo = sb[c], cnt = sb[c + 1] - sb[c];
     if (cnt > 0) {
@@ -2002,6 +2072,9 @@ int pdlp_iterate(pdlp_handle h, int iters, int adaptive)
 {
     if (!h || iters < 0) return PDLP_ERR_INVALID;
     adaptive = adaptive ? 1 : 0;
+    char rname[64];
+    if (g_roctx.level > 0) std::snprintf(rname, sizeof rname, "pdlp: %d %s iterations", iters, adaptive ? "adaptive" : "fixed-step");
+    Range range(rname, h->stream);
     if (h->comm) return iterate_sharded(h, iters, adaptive);
     if (h->nl != h->p.n || h->ml != h->p.m) return PDLP_ERR_STATE;   // sharded without a communicator: the caller does the exchange
     int rc, left = iters;
@@ -2054,6 +2127,7 @@ int pdlp_compute_average(pdlp_handle h)
 int pdlp_kkt_local(pdlp_handle h, int which, int unscaled)
 {
     if (!h || which < PDLP_CUR || which > PDLP_PREV) return PDLP_ERR_INVALID;
+    Range range(which == PDLP_CUR ? "pdlp: KKT pass (current)" : which == PDLP_AVG ? "pdlp: KKT pass (average)" : "pdlp: KKT pass (previous)", h->stream);
     if (unscaled && (!h->p.d_col || !h->p.d_row)) return PDLP_ERR_STATE;
     if (h->delta) return delta_kkt_local(h, which, unscaled);
     return DISPATCH(h, kkt_local_t, h, which, unscaled);
@@ -2213,6 +2287,7 @@ int pdlp_spmv(pdlp_handle h, int transpose, const void* in_full, void* out_local
 int pdlp_power_iteration(pdlp_handle h, const void* b0, int iters, void* work_n, void* work_m, double* sigma)
 {
     if (!h || !b0 || !work_n || !work_m || !sigma || iters < 0) return PDLP_ERR_INVALID;
+    Range range("pdlp: power iteration", h->stream);
     if (h->nl != h->p.n || h->ml != h->p.m) return PDLP_ERR_STATE;
     return DISPATCH(h, power_iteration_t, h, b0, iters, work_n, work_m, sigma);
 }
@@ -2233,6 +2308,7 @@ int pdlp_set_delta(pdlp_handle h, int on)
 int pdlp_refresh_products(pdlp_handle h)
 {
     if (!h) return PDLP_ERR_INVALID;
+    Range range("pdlp: exact products (anchors / K x cache)", h->stream);
     if (h->delta) return delta_refresh(h);
     if (h->p.dtype == PDLP_F32) return refresh_kx_t<float>(h);
     return refresh_kx_t<double>(h);
@@ -2277,6 +2353,36 @@ int pdlp_probe_stream_read(const void* buf, int64_t bytes, int reps, void* strea
     HIP_TRY(hipGetLastError());
     const size_t per = n16 / grid, read16 = per / (4 * 512) * (4 * 512) * grid;      // what the kernel really loads
     *gb_per_s = (double)read16 * 16.0 * reps / ((double)ms * 1e-3) / 1e9;
+    return PDLP_OK;
+}
+
+int pdlp_trace_enable(int level)
+{
+    if (level < 0 || level > 2) return PDLP_ERR_INVALID;
+    if (level > 0) {
+        roctx_load();
+        if (!g_roctx.push) { g_roctx.level = 0; return PDLP_ERR_STATE; }       // no roctx library on this machine
+    }
+    g_roctx.level = level;
+    return PDLP_OK;
+}
+
+int pdlp_range_push(const char* name, void* stream)
+{
+    if (!name) return PDLP_ERR_INVALID;
+    if (g_roctx.level > 0 && g_roctx.push) {
+        if (g_roctx.level > 1) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        (void)g_roctx.push(name);
+    }
+    return PDLP_OK;
+}
+
+int pdlp_range_pop(void* stream)
+{
+    if (g_roctx.level > 0 && g_roctx.pop) {
+        if (g_roctx.level > 1) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        (void)g_roctx.pop();
+    }
     return PDLP_OK;
 }
 

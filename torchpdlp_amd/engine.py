@@ -106,6 +106,7 @@ class PdlpEngine:
         of delta mode are then evaluated with it (a second, float64 CSR handle over the same row blocks; ``pdlp_set_anchors``).
         A scaled matrix whose entries ARE float32 numbers (Ruiz on a +-1 matrix is the identity) needs no ``exact``."""
         self.lib = N.load()
+        N.trace_range.enabled()                # (PDLP_ROCTX=1|2: roctx ranges for rocprofv3 --marker-trace; once per process)
         rows = (0, m) if rows is None else rows
         cols = (0, n) if cols is None else cols
         self.m, self.n, self.m_ineq = int(m), int(n), int(m_ineq)
@@ -222,9 +223,10 @@ class PdlpEngine:
             if mode == "auto" and nnz < 10 * rows:
                 continue
             knob = lambda name: int(os.environ[name]) if os.environ.get(name) else None      # tuning experiments
-            t = _tiled.build_tiles(rp, ci, va, rows, cols, lw=knob("PDLP_TILE_LW"), rpt=knob("PDLP_TILE_RPT"),
-                                   groups=knob("PDLP_TILE_GROUPS"), max_groups=lim["max_groups"],
-                                   kernel_limits=(lim["rpt_max"], lim["cap"], lim["nt"]))
+            with N.trace_range("pdlp: tile build (K')" if transpose else "pdlp: tile build (K)", self.stream):
+                t = _tiled.build_tiles(rp, ci, va, rows, cols, lw=knob("PDLP_TILE_LW"), rpt=knob("PDLP_TILE_RPT"),
+                                       groups=knob("PDLP_TILE_GROUPS"), max_groups=lim["max_groups"],
+                                       kernel_limits=(lim["rpt_max"], lim["cap"], lim["nt"]))
             if t is None or t.nblk > lim["max_blocks"]:
                 # clustered (banded, block structured): the CSR kernel, with every row block's items sorted by column
                 if t is None and os.environ.get("PDLP_SORTED", "auto") != "0":
@@ -690,6 +692,11 @@ class PdlpEngine:
                 N.check(lib.pdlp_adaptive_update(h), "pdlp_adaptive_update")
         if not adaptive and iters > 0:
             N.check(self.lib.pdlp_fixed_advance(self.h, int(iters)), "pdlp_fixed_advance")
+
+    def adaptive_retry(self):
+        """discard the adaptive iteration just taken (its trial was rejected: ``scalars()["accepted"] == 0``) so that it can be
+        issued again with the shrunk step size -- ``pdlp_adaptive_retry`` (include/pdlp_hip.h), SURVEY quirk Q1's optional flag"""
+        N.check(self.lib.pdlp_adaptive_retry(self.h), "pdlp_adaptive_retry")
 
     # ---- restart machinery --------------------------------------------------------------------------
     def flush_average(self, adaptive: bool = True):

@@ -36,29 +36,31 @@ def _sweeps(lib, code, stream, rows_K, rows_KT, K_blk, KT_blk, D_row, D_col, max
     work = torch.zeros(1, dtype=torch.float64, device=dev)
     nnz_K, nnz_KT = int(va.numel()), int(t_va.numel())
     sweeps = 0
+    tstream = torch.cuda.current_stream(dev)
     for _ in range(int(max_iter)):
-        sweeps += 1
-        N.check(lib.pdlp_csr_row_scale_factors(code, rows_K, p(rp), p(va), float(eps), p(rn), stream), "row factors")            # :49-50
-        N.check(lib.pdlp_vec_muldiv(code, rows_K, p(D_row), p(rn), 1, stream), "D_row /= r")                                     # :51
-        N.check(lib.pdlp_csr_div_rows(code, rows_K, p(rp), p(va), p(rn), stream), "K rows /= r")                                 # :52
-        if comm is not None:
-            comm.all_gather(rn_full)
-        N.check(lib.pdlp_csr_div_cols(code, nnz_KT, p(t_ci), p(t_va), p(rn_full), stream), "K' cols /= r")
-        N.check(lib.pdlp_csr_row_scale_factors(code, rows_KT, p(t_rp), p(t_va), float(eps), p(cn), stream), "col factors")       # :54-55
-        N.check(lib.pdlp_vec_muldiv(code, rows_KT, p(D_col), p(cn), 1, stream), "D_col /= c")                                    # :56
-        N.check(lib.pdlp_csr_div_rows(code, rows_KT, p(t_rp), p(t_va), p(cn), stream), "K' rows /= c")                           # :57
-        if comm is not None:
-            comm.all_gather(cn_full)
-        N.check(lib.pdlp_csr_div_cols(code, nnz_K, p(ci), p(va), p(cn_full), stream), "K cols /= c")
-        dev_from_one = C.c_double(0)
-        N.check(lib.pdlp_vec_max_dev_from_one(code, rows_K, p(rn), p(work), C.byref(dev_from_one), stream), "max|1-r|")          # :60-61
-        worst = dev_from_one.value
-        if comm is not None:
-            w = torch.tensor([worst], dtype=torch.float64, device=dev)
-            comm.all_reduce_max(w)
-            worst = float(w)
-        if worst < eps:
-            break
+        with N.trace_range(f"pdlp: Ruiz sweep {sweeps + 1}", tstream):
+            sweeps += 1
+            N.check(lib.pdlp_csr_row_scale_factors(code, rows_K, p(rp), p(va), float(eps), p(rn), stream), "row factors")            # :49-50
+            N.check(lib.pdlp_vec_muldiv(code, rows_K, p(D_row), p(rn), 1, stream), "D_row /= r")                                     # :51
+            N.check(lib.pdlp_csr_div_rows(code, rows_K, p(rp), p(va), p(rn), stream), "K rows /= r")                                 # :52
+            if comm is not None:
+                comm.all_gather(rn_full)
+            N.check(lib.pdlp_csr_div_cols(code, nnz_KT, p(t_ci), p(t_va), p(rn_full), stream), "K' cols /= r")
+            N.check(lib.pdlp_csr_row_scale_factors(code, rows_KT, p(t_rp), p(t_va), float(eps), p(cn), stream), "col factors")       # :54-55
+            N.check(lib.pdlp_vec_muldiv(code, rows_KT, p(D_col), p(cn), 1, stream), "D_col /= c")                                    # :56
+            N.check(lib.pdlp_csr_div_rows(code, rows_KT, p(t_rp), p(t_va), p(cn), stream), "K' rows /= c")                           # :57
+            if comm is not None:
+                comm.all_gather(cn_full)
+            N.check(lib.pdlp_csr_div_cols(code, nnz_K, p(ci), p(va), p(cn_full), stream), "K cols /= c")
+            dev_from_one = C.c_double(0)
+            N.check(lib.pdlp_vec_max_dev_from_one(code, rows_K, p(rn), p(work), C.byref(dev_from_one), stream), "max|1-r|")          # :60-61
+            worst = dev_from_one.value
+            if comm is not None:
+                w = torch.tensor([worst], dtype=torch.float64, device=dev)
+                comm.all_reduce_max(w)
+                worst = float(w)
+            if worst < eps:
+                break
     return sweeps
 
 

@@ -70,10 +70,15 @@ class PdhgDriver:
     """
 
     def __init__(self, eng: PdlpEngine, restart_period=40, primal_update=False, adaptive=False, precondition=False,
-                 tol=1e-4, verbose=False, trace=None, infeasibility_detect=False, infeas_tol=1e-4):
+                 tol=1e-4, verbose=False, trace=None, infeasibility_detect=False, infeas_tol=1e-4, adaptive_retry=False):
         self.eng, self.period = eng, int(restart_period)
         self.infeasibility_detect, self.infeas_tol = bool(infeasibility_detect), float(infeas_tol)
         self.infeasible = None                                              # the detector's verdict (pdhg.py:94-100)
+        # SURVEY quirk Q1's optional flag: the adaptive step as it was meant (enhancements/test_ass.py:322-363) -- a rejected trial is
+        # discarded and repeated with the shrunk step size until one is accepted (at most 200, like the reference's loop bound);
+        # one KKT-pass count per trial (step.py:93 sits inside the loop).  Off: the live package's single trial (a rejected step is kept)
+        self.adaptive_retry = bool(adaptive_retry) and bool(adaptive)
+        self.trials = 0
         self.primal_update, self.adaptive, self.precondition = bool(primal_update), bool(adaptive), bool(precondition)
         self.tol, self.verbose, self.trace = tol, verbose, trace
         self.t = _np_t(eng.dtype)
@@ -128,6 +133,24 @@ class PdhgDriver:
                     break
                 if self.j - j0 >= int(max_iters):                           # pdhg.py:67
                     return iters
+        elif self.adaptive_retry:
+            iters = min(self.period - self.tt % self.period, int(max_iters))
+            if iters <= 0:
+                return 0
+            for _ in range(iters):
+                trials = 0
+                while True:
+                    eng.iterate(1, True)
+                    trials += 1
+                    if trials >= 200 or eng.scalars()["accepted"]:         # (one host read per trial: this mode is not the fast path)
+                        break
+                    eng.adaptive_retry()
+                self.j += trials
+                self.trials += trials
+            self.k += iters
+            self.tt += iters
+            if self.tt % self.period != 0:
+                return iters
         else:
             iters = min(self.period - self.tt % self.period, int(max_iters))
             if iters <= 0:
@@ -143,6 +166,8 @@ class PdhgDriver:
             eng.synchronize()
             t_check = time.perf_counter()
         self.checks += 1
+        check_range = N.trace_range("pdlp: restart check (3 KKT evaluations)", eng.stream)
+        check_range.__enter__()
         # the current iterate first: its pass keeps K'y, which closes the running sum of K'y_k -- the averaged iterate then
         # needs no product at all (K x_avg and K'y_avg come out of the sums; include/pdlp_hip.h, pdlp_flush_average)
         r_cur = eng.kkt(N.CUR, self.omega)                                  # pdhg.py:122-125
@@ -168,14 +193,16 @@ class PdhgDriver:
             crit = 1
         elif self.tt >= self.beta[2] * self.k:                              # artificial, pdhg.py:139
             crit = 2
+        check_range.__exit__(None, None, None)
         if crit >= 0:
             if self.verbose:
                 print(f"{('Sufficient', 'Necessary', 'Artificial')[crit]} restart at iteration {self.tt} using the",
                       "Average iterate." if use_avg else "Current iterate.")
             if self.trace is not None:
                 self.trace["restarts"].append((crit, self.tt, int(use_avg)))
-            eng.restart(N.AVG if use_avg else N.CUR)
-            self.after_restart(r_avg if use_avg else r_cur)
+            with N.trace_range("pdlp: restart work (restart, primal weight, termination test)", eng.stream):
+                eng.restart(N.AVG if use_avg else N.CUR)
+                self.after_restart(r_avg if use_avg else r_cur)
         if timed:
             eng.synchronize()
             self.check_seconds += time.perf_counter() - t_check
@@ -237,11 +264,14 @@ def estimate_sigma(eng: PdlpEngine, b0=None, power_iters=100, seed=None) -> floa
 
 def run_pdlp(eng: PdlpEngine, max_kkt=100_000, tol=1e-4, verbose=True, restart_period=40, precondition=False,
              primal_update=False, adaptive=False, time_limit=3600, time_used=0, x_init=None, y_init=None,
-             b0=None, sigma=None, power_iters=100, seed=None, trace=None, infeasibility_detect=False, infeas_tol=1e-4):
+             b0=None, sigma=None, power_iters=100, seed=None, trace=None, infeasibility_detect=False, infeas_tol=1e-4,
+             adaptive_retry=False):
     """The outer loop over an existing engine.  Returns (x_local, prim_obj, k, n, j, status, total_time)."""
     t0 = time.time()
+    if adaptive_retry and (getattr(eng, "delta", False) or infeasibility_detect):
+        raise ValueError("adaptive_retry works on float32 / float64 engines without the infeasibility detector")
     drv = PdhgDriver(eng, restart_period, primal_update, adaptive, precondition, tol, verbose, trace,
-                     infeasibility_detect, infeas_tol)
+                     infeasibility_detect, infeas_tol, adaptive_retry=adaptive_retry)
     if sigma is None:                                                       # pdhg.py:22
         sigma = estimate_sigma(eng, b0, power_iters, seed)
     drv.start(sigma, x_init, y_init)
@@ -290,7 +320,7 @@ def run_pdlp(eng: PdlpEngine, max_kkt=100_000, tol=1e-4, verbose=True, restart_p
 def pdlp_algorithm(K, m_ineq, c, q, l, u, device=None, max_kkt=100_000, tol=1e-4, verbose=True, restart_period=40,
                    precondition=False, primal_update=False, adaptive=False, data_precond=None, infeasibility_detect=False,
                    infeas_tol=1e-4, time_limit=3600, time_used=0, x_init=None, y_init=None, *, b0=None, sigma=None,
-                   seed=None, trace=None, comm=None, precision=None):
+                   seed=None, trace=None, comm=None, precision=None, adaptive_retry=False):
     """Drop-in for the reference's ``pdlp_algorithm`` (primal_dual_hybrid_gradient.py:7) on one MI355X.
 
     ``K`` may be a dense / COO torch tensor (as the reference takes), a scipy sparse matrix or a
@@ -299,6 +329,10 @@ def pdlp_algorithm(K, m_ineq, c, q, l, u, device=None, max_kkt=100_000, tol=1e-4
     ``seed`` pin the power-iteration start the reference leaves to an unseeded RNG.
     Returns ``(x, prim_obj, k, n, j, status, total_time)``; ``x`` is an (n,1) tensor and, like the
     reference's (quirk Q4), the SCALED iterate when preconditioned.
+
+    ``adaptive_retry`` (with ``adaptive``; default off = the live package's behaviour, quirk Q1): the adaptive step as it was
+    meant -- a rejected trial is repeated from the same iterate with the shrunk step size until one is accepted
+    (/root/reference/enhancements/test_ass.py:322-363) instead of being kept.
 
     ``precision="mixed"``: float64 vectors, products and sums over a matrix held in float32 -- for tolerances below float32
     resolution (the reference is float32 only) on matrices whose entries are float32 numbers (checked); 8 instead of 12 bytes
@@ -351,10 +385,10 @@ def pdlp_algorithm(K, m_ineq, c, q, l, u, device=None, max_kkt=100_000, tol=1e-4
         x, obj, k, n, j, status, total = run_pdlp(eng, max_kkt, tol, verbose, restart_period, precondition, primal_update,
                                                   adaptive, time_limit, time_used, x_init, y_init, b0=b0, sigma=sigma,
                                                   seed=seed, trace=trace, infeasibility_detect=infeasibility_detect,
-                                                  infeas_tol=infeas_tol)
+                                                  infeas_tol=infeas_tol, adaptive_retry=adaptive_retry)
         return gather_solution(eng, x, Kp.n).view(-1, 1), obj, k, n, j, status, total
     eng = PdlpEngine.from_full(Kp, c, q, l, u, m_ineq, d_col=d_col, d_row=d_row, vec_dtype=vec_dtype, exact=exact_K)
     x, obj, k, n, j, status, total = run_pdlp(eng, max_kkt, tol, verbose, restart_period, precondition, primal_update, adaptive,
                                               time_limit, time_used, x_init, y_init, b0=b0, sigma=sigma, seed=seed, trace=trace,
-                                              infeasibility_detect=infeasibility_detect, infeas_tol=infeas_tol)
+                                              infeasibility_detect=infeasibility_detect, infeas_tol=infeas_tol, adaptive_retry=adaptive_retry)
     return x.view(-1, 1), obj, k, n, j, status, total
