@@ -155,7 +155,7 @@ def test_chosen_groups_fit_the_rowsum_scratch():
     for rows in (200_000, 1_250_000, 5_000_000, 10_000_000, 10_485_760, 10_485_761, 10_600_000, 12_000_000, 15_000_000,
                  20_000_000, 30_000_000):
         lim = T.rowsum_groups(rows)
-        assert lim == (24 if rows <= 512 * 40 * 128 else 8 if rows <= 512 * 40 * 512 else 1)
+        assert lim == (32 if rows <= 512 * 40 * 128 else 8 if rows <= 512 * 40 * 512 else 1)
         for per_row in (5, 20, 50):
             for rpt_max, cap in ((T.RPT_MAX, T.CAP), (T.RPT_MAX_F64, T.CAP_F64)):
                 for cols in (rows, 4 * rows, rows // 4):

@@ -155,7 +155,7 @@ class trace_range:
     def enabled(cls) -> bool:
         if cls.level is None:
             lvl = int(os.environ.get("PDLP_ROCTX", "0") or 0)
-            cls.level = lvl if lvl > 0 and load().pdlp_trace_enable(lvl) == 0 else 0
+            cls.level = lvl if lvl > 0 and os.path.exists(LIB_PATH) and load().pdlp_trace_enable(lvl) == 0 else 0
         return cls.level > 0
 
     def __enter__(self):

@@ -387,11 +387,10 @@ void launch_tiled_groups(pdlp_handle h, const Schedule& s, int rows, const void*
 {
     if (nbl < 0) nbl = s.t.nblk - b0;                     // (default: every row block)
     if (vtotal <= 0 || vgroups <= 0 || nbl <= 0) return;
-    const int ppg = (vtotal + vgroups - 1) / vgroups;
-    const int groups = (vtotal + ppg - 1) / ppg;          // no group without panels
+    const int groups = vgroups < vtotal ? vgroups : vtotal;       // (the kernel splits the panels evenly: no group without panels)
     StoreEpi<T> none{nullptr};
     hipLaunchKernelGGL((k_tiled_fused<T, TV, StoreEpi<T>, false>), dim3(nbl * groups), dim3(TNT), 0, stream, s.t.idx,
-                       (const TV*)s.t.val, s.t.tile_ptr, s.t.blk_base, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, ppg, vtotal, ptab,
+                       (const TV*)s.t.val, s.t.tile_ptr, s.t.blk_base, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, vtotal, ptab,
                        slot0, b0, nbl, (const T*)vin, (T*)h->rowsum, h->rs_stride, (const T*)nullptr, none, (double*)nullptr);
 }
 
@@ -450,7 +449,7 @@ int launch_mat(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* 
         }
         if (s.t.groups == 1 && !(s.pending && h->use_split)) {
             hipLaunchKernelGGL((k_tiled_fused<T, TV, Epi, true>), dim3(s.t.nblk), dim3(TNT), 0, h->stream, s.t.idx, (const TV*)s.t.val,
-                               s.t.tile_ptr, s.t.blk_base, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, s.t.npanel, s.t.npanel,
+                               s.t.tile_ptr, s.t.blk_base, s.t.cnt, s.t.npanel, s.t.lw, s.t.rpt, rows, s.t.nblk, s.t.npanel,
                                (const int32_t*)nullptr, 0, 0, s.t.nblk, (const T*)vin, (T*)h->rowsum, h->rs_stride, extra, epi, partials);
         } else if (s.pending && h->use_split) {
             // the local panels were multiplied by pdlp_*_half_begin on the side stream (and the first chunks' panels by
@@ -765,7 +764,11 @@ int configure_split(pdlp_handle h, bool transpose)
     const int round_slots = 2 * 256;
     int fit = round_slots / (s.t.nblk > 0 ? s.t.nblk : 1);
     fit = fit < 1 ? 1 : fit;
-    auto norm = [](int g, int n) { if (n <= 0) return 0; g = g < 1 ? 1 : (g > n ? n : g); const int ppg = (n + g - 1) / g; return (n + ppg - 1) / ppg; };
+    // Group counts are powers of two: the group is the fast index of blockIdx and workgroups are dealt round-robin over the 8 XCDs,
+    // so with 8 (16) groups each XCD's L2 holds the panels of one (two) groups only, with 2 or 4 groups of two or four -- any other
+    // count spreads every group over all XCDs and each of them pulls the whole gathered vector (measured: k_tiled_fused).
+    auto pow2 = [](int g) { int p = 1; while (2 * p <= g) p *= 2; return p; };
+    auto norm = [&](int g, int n) { if (n <= 0) return 0; g = g < 1 ? 1 : (g > n ? n : g); return pow2(g); };
     int a = (nloc + 12) / 13;
     a = a > fit ? fit : a;
     a = a > nloc ? nloc : a;
@@ -1234,7 +1237,7 @@ int check_problem(const pdlp_problem* p)
 // cannot fill 2 x 256 CUs, i.e. below about 10.5M rows
 inline int64_t rowsum_groups(int64_t rows)
 {
-    if (rows <= (int64_t)512 * 40 * 128) return 24;               // (small shards: room for the local panels and several chunks' groups)
+    if (rows <= (int64_t)512 * 40 * 128) return 32;               // (small shards: room for the local panels and several chunks' groups)
     return rows <= (int64_t)512 * 40 * 512 ? 8 : 1;
 }
 
@@ -1519,8 +1522,7 @@ int pdlp_attach_tiles(pdlp_handle h, int transpose, const pdlp_tiles* t)
     if (t->nblk != (int)((rows + rb - 1) / rb) || t->npanel < 1) return PDLP_ERR_INVALID;
     if (t->groups < 1 || t->groups > h->rs_groups || t->groups > t->npanel) return PDLP_ERR_INVALID;
     if (t->nblk > h->part_blocks) return PDLP_ERR_INVALID;             // one slot of partial sums per workgroup
-    const int ppg = (t->npanel + t->groups - 1) / t->groups;
-    if ((t->groups - 1) * ppg >= t->npanel) return PDLP_ERR_INVALID;     // every group must own at least one panel
+    // (every group owns at least one panel: the kernel splits the panels evenly, groups <= npanel was checked above)
     if (!t->idx || !t->val || !t->tile_ptr || !t->blk_base || !t->cnt) return PDLP_ERR_INVALID;
     if (((uintptr_t)t->idx & 15u) || ((uintptr_t)t->val & 15u) || ((uintptr_t)t->cnt & 15u)) return PDLP_ERR_INVALID;
     if (t->rem_rows_n < 0 || t->rem_segs_n < t->rem_rows_n) return PDLP_ERR_INVALID;

@@ -166,7 +166,7 @@ class PdhgDriver:
             eng.synchronize()
             t_check = time.perf_counter()
         self.checks += 1
-        check_range = N.trace_range("pdlp: restart check (3 KKT evaluations)", eng.stream)
+        check_range = N.trace_range("pdlp: restart check (3 KKT evaluations)", getattr(eng, "stream", None))
         check_range.__enter__()
         # the current iterate first: its pass keeps K'y, which closes the running sum of K'y_k -- the averaged iterate then
         # needs no product at all (K x_avg and K'y_avg come out of the sums; include/pdlp_hip.h, pdlp_flush_average)
@@ -200,7 +200,7 @@ class PdhgDriver:
                       "Average iterate." if use_avg else "Current iterate.")
             if self.trace is not None:
                 self.trace["restarts"].append((crit, self.tt, int(use_avg)))
-            with N.trace_range("pdlp: restart work (restart, primal weight, termination test)", eng.stream):
+            with N.trace_range("pdlp: restart work (restart, primal weight, termination test)", getattr(eng, "stream", None)):
                 eng.restart(N.AVG if use_avg else N.CUR)
                 self.after_restart(r_avg if use_avg else r_cur)
         if timed:

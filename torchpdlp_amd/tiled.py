@@ -124,7 +124,7 @@ def rowsum_groups(rows: int) -> int:
     (``rowsum_groups`` in csrc/pdlp_hip.hip; ``pdlp_tile_limits`` reports the same number for a live handle): splitting a
     row block's panels over several workgroups only pays while one workgroup per row block cannot fill 2 x 256 CUs"""
     if rows <= 512 * 40 * 128:
-        return 24               # (small shards: the local panels' groups plus those of every chunk of a chunked exchange)
+        return 32               # (small shards: the local panels' groups plus those of every chunk of a chunked exchange)
     return 8 if rows <= 512 * 40 * 512 else 1
 
 
