@@ -379,6 +379,8 @@ def measure_roofline(args, eng, dt, adaptive, world):
     roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, launch_ms=round(kms, 4),
                     algorithmic_bytes=int(kbytes), other_kernel_ms=round(min(ms_primal, ms_dual), 4))
+    if traffic is not None:       # (PMC counters need their own rocprofv3 passes: this is the recorded value of that profile run)
+        roofline["traffic_source"] = "recorded: profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration), not measured in this run"
     # the device's streaming-read ceiling beside the nominal peak -- measured in THIS run (pdlp_probe_stream_read: the tiled
     # kernel's access pattern over a 2 GiB zero buffer, 5 launches); the recorded probe of profiles/ only if that fails
     try:
