@@ -59,7 +59,8 @@ def test_spawn_ranks_relays_a_measured_line_when_ranks_hang_afterwards(tmp_path,
     """)
     rc = bench.spawn_ranks(2, [], script=script, grace=1.0)
     out, err = capfd.readouterr()
-    assert rc == 0 and json.loads(out.strip())["value"] == 1.5
+    line = json.loads(out.strip())
+    assert rc == 0 and line["value"] == 1.5 and line["degraded"] is True and "still running" in line["degraded_reason"]
     assert "stopping the ranks" in err
 
 
@@ -81,7 +82,9 @@ def test_spawn_ranks_keeps_the_line_when_a_rank_fails_after_it(tmp_path, capfd):
     """)
     rc = bench.spawn_ranks(2, [], script=script)
     out, err = capfd.readouterr()
-    assert rc == 0 and json.loads(out.strip())["value"] == 2.5 and "measured before the failure" in err
+    line = json.loads(out.strip())
+    assert rc == 0 and line["value"] == 2.5 and "measured before the failure" in err
+    assert line["degraded"] is True and "exited with code 7" in line["degraded_reason"]        # (a salvaged line says so itself)
 
 
 def test_spawn_ranks_hosts_the_rendezvous_store(tmp_path, capfd):
