@@ -59,6 +59,16 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert lib.pdlp_vec_muldiv(7, 1, None, None, 0, None) == -1      # bad dtype code
     with pytest.raises(N.PdlpError):
         N.check(-1, "demo")
+    # round 5's entry points reject nonsense as well (no handle needed to see that)
+    assert lib.pdlp_set_option(None, N.OPT_GRAPH, 1) == -1
+    assert lib.pdlp_adaptive_retry(None) == -1
+    assert lib.pdlp_primal_half_piece(None, 1, 0, 2) == -1 and lib.pdlp_dual_half_piece(None, 1, 0, 2) == -1
+    assert lib.pdlp_mv_product(None, 8, None, None) == -1
+    assert lib.pdlp_mv_combine(N.PDLP_F32, 10, 33, None, None, 1, None, None) == -1          # more than 32 columns
+    assert lib.pdlp_vec_sqdist(7, 1, None, None, None, None, None) == -1
+    assert lib.pdlp_probe_gather(None, 0, 10, 1, None, None) == -1
+    assert lib.pdlp_trace_enable(7) == -1 and lib.pdlp_trace_enable(0) == 0
+    assert lib.pdlp_range_push(None, None) == -1 and lib.pdlp_range_pop(None) == 0            # (tracing off: a pop is a no-op)
 
 
 def test_product_path_fails_loudly_off_the_gpu_and_without_the_library(monkeypatch, tmp_path):
