@@ -1987,8 +1987,9 @@ int iterate_sharded(pdlp_handle h, int iters, int adaptive)
         // and runs while the handle's stream multiplies the panels the pieces complete (same sums, same values: only the order in
         // which independent work is enqueued changes)
         const bool ar_early = adaptive && sent && h->ev_ar;
+        // (the kernel that adds up this rank's three sums needs only the half-steps' partial sums: it runs while y is on the wire)
+        if (adaptive && (rc = pdlp_adaptive_reduce(h)) != PDLP_OK) return rc;
         if (ar_early) {
-            if ((rc = pdlp_adaptive_reduce(h)) != PDLP_OK) return rc;
             HIP_TRY(hipEventRecord(h->ev_vec, h->stream));
             HIP_TRY(hipStreamWaitEvent(h->cstream, h->ev_vec, 0));
             RCCL_TRY(g_rccl.AllReduce(h->red, h->red, 3, ncclFloat64, ncclSum, h->comm, h->cstream));
@@ -2001,7 +2002,6 @@ int iterate_sharded(pdlp_handle h, int iters, int adaptive)
             HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_ar, 0));
             if ((rc = pdlp_adaptive_update(h)) != PDLP_OK) return rc;
         } else if (adaptive) {
-            if ((rc = pdlp_adaptive_reduce(h)) != PDLP_OK) return rc;
             RCCL_TRY(g_rccl.AllReduce(h->red, h->red, 3, ncclFloat64, ncclSum, h->comm, h->stream));
             if ((rc = pdlp_adaptive_update(h)) != PDLP_OK) return rc;
         }

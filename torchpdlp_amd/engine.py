@@ -675,17 +675,18 @@ class PdlpEngine:
             ynew = gdy if self.delta else self.buffer(N.BUF_Y_PREV)     # where the dual half-step writes (the buffers alternate)
             wy = self._half_in_pieces(True, a, ynew)
             ar = None
-            if adaptive and wy is not None:
-                # the step-size rule's three sums queue up behind the pieces of y and are reduced while the panels those pieces
-                # complete are multiplied (same sums: only the order in which independent work is issued differs)
+            if adaptive:
+                # the rank's three sums of the step-size rule need only this iteration's partial sums: the kernel that adds them up
+                # runs while y is on the wire.  With pieces their all-reduce queues up behind the pieces and is reduced while the
+                # panels those pieces complete are multiplied (same sums: only the order in which independent work is issued differs)
                 N.check(lib.pdlp_adaptive_reduce(h), "pdlp_adaptive_reduce")
-                ar = comm.all_reduce_sum_async(red)
+                if wy is not None:
+                    ar = comm.all_reduce_sum_async(red)
             if it + 1 < iters:                             # (the new y is final: a rejected adaptive step is kept, quirk Q1)
                 N.check(lib.pdlp_primal_half_begin(h), "pdlp_primal_half_begin")
             self._exchange(1, ynew, wy)                    # (no product under way after the last iteration: the pieces just arrive)
             if adaptive:
                 if wy is None:
-                    N.check(lib.pdlp_adaptive_reduce(h), "pdlp_adaptive_reduce")
                     comm.all_reduce_sum(red)
                 elif ar is not None:
                     ar.wait()
