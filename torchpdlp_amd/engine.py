@@ -159,8 +159,8 @@ class PdlpEngine:
         if os.environ.get("PDLP_NO_KTY_REUSE") is not None:
             self.set_option(N.OPT_KTY_REUSE, 0)
         self.producer_pieces = os.environ.get("PDLP_PRODUCER_PIECES", "1")[:1] != "0"
-        if os.environ.get("PDLP_PRODUCER_PIECES", "1") != "1":
-            self.set_option(N.OPT_PRODUCER_PIECES, int(os.environ["PDLP_PRODUCER_PIECES"]))
+        if not self.producer_pieces:
+            self.set_option(N.OPT_PRODUCER_PIECES, 0)
         if os.environ.get("PDLP_GRAPH") is not None and self.comm is None:
             self.set_option(N.OPT_GRAPH, 1)
         self.exact = None
