@@ -737,6 +737,17 @@ def main(argv=None):
     if args.solve_tol > 0:
         # time to tolerance (untimed part of the run, the engine of the timed region re-started from zero): the reference's default
         # tolerance fits a bench run; tighter ones are separate runs (tools/time_to_tol.py), recorded in profiles/time_to_tol.json
+        # (a solve of several minutes says nothing by itself: a line on stderr every minute shows a supervisor that it is alive)
+        import threading
+        beat_stop = threading.Event()
+
+        def beat():
+            t_beat = time.time()
+            while not beat_stop.wait(60.0):
+                sys.stderr.write(f"bench.py: rank {rank}: time-to-tolerance solve (tol {args.solve_tol:g}) running, {time.time() - t_beat:.0f} s\n")
+                sys.stderr.flush()
+        if rank == 0:
+            threading.Thread(target=beat, daemon=True).start()
         try:
             from torchpdlp_amd.solver import run_pdlp
             _, obj, it, nr, jj, status, secs = run_pdlp(eng, tol=args.solve_tol, verbose=False, primal_update=True, adaptive=adaptive,
@@ -752,6 +763,7 @@ def main(argv=None):
             out["time_to_tol"] = ttt
         except Exception as e:
             out["time_to_tol"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        beat_stop.set()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         del eng
         torch.cuda.empty_cache()
