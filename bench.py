@@ -170,6 +170,8 @@ def parse(argv=None):
                    help="after the timed region: a full restarted solve of the same LP to this relative KKT tolerance (the second half "
                         "of BASELINE's metric, reported as time_to_tol; N=1 only; 0 = skip)")
     p.add_argument("--solve-limit", type=float, default=120.0, help="time limit of that solve, seconds")
+    p.add_argument("--solve-max-kkt", type=int, default=100_000,
+                   help="KKT-pass cap of that solve (the reference's max_kkt; the 10M LP needs ~152k passes to reach 1e-8)")
     p.add_argument("--cpu-sample-rows", type=int, default=4_000_000,
                    help="most rows (= columns) of the CPU baseline's sample; the host's free memory may lower it")
     p.add_argument("--kernel-reps", type=int, default=20)
@@ -750,7 +752,7 @@ def main(argv=None):
             threading.Thread(target=beat, daemon=True).start()
         try:
             from torchpdlp_amd.solver import run_pdlp
-            _, obj, it, nr, jj, status, secs = run_pdlp(eng, tol=args.solve_tol, verbose=False, primal_update=True, adaptive=adaptive,
+            _, obj, it, nr, jj, status, secs = run_pdlp(eng, max_kkt=args.solve_max_kkt, tol=args.solve_tol, verbose=False, primal_update=True, adaptive=adaptive,
                                                         precondition=args.ruiz, time_limit=args.solve_limit, seed=0, power_iters=100)
             ttt = {"tol": args.solve_tol, "seconds": round(max_over_ranks(secs), 2), "iterations": int(it), "restarts": int(nr),
                    "kkt_passes": int(jj), "status": status, "objective": float(obj), "n_gpus": world,
