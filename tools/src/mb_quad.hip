@@ -62,6 +62,53 @@ __global__ __launch_bounds__(NTHR, 4) void k_sg(const u32x4* __restrict__ idx, c
     if (acc == 123.456f) out[0] = acc;
 }
 
+// the same loop with the gathers as per-lane LDS-DMA (global_load_lds_dword: the dword of lane L lands at lds[base + 4 L], no VGPR
+// return path) followed by a conflict-free ds_read of the lane's own slot: does the direct-to-LDS path handle scattered lines faster?
+template <int NTHR, int UNROLL>
+__global__ __launch_bounds__(NTHR, 4) void k_sg_ldsdma(const u32x4* __restrict__ idx, const f32x4* __restrict__ val,
+                                                       const float* __restrict__ table, size_t n16, float* out)
+{
+    __shared__ float stage[NTHR / 64][4][64];
+    const size_t per = n16 / gridDim.x;
+    const u32x4* pi = idx + (size_t)blockIdx.x * per;
+    const f32x4* pv = val + (size_t)blockIdx.x * per;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float acc = 0.f;
+    for (size_t i = threadIdx.x; i + (UNROLL - 1) * NTHR < per; i += NTHR * UNROLL) {
+        u32x4 k[UNROLL];
+        f32x4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) { k[u] = __builtin_nontemporal_load(pi + i + u * NTHR); v[u] = __builtin_nontemporal_load(pv + i + u * NTHR); }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const unsigned c[4] = {k[u].x, k[u].y, k[u].z, k[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(table + c[j]),
+                                                 (__attribute__((address_space(3))) void*)&stage[wv][j][0], 4, 0, 0);
+            __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): the four LDS-DMA gathers have landed
+            const float g0 = stage[wv][0][lane], g1 = stage[wv][1][lane], g2 = stage[wv][2][lane], g3 = stage[wv][3][lane];
+            acc += v[u].x * g0 + v[u].y * g1 + v[u].z * g2 + v[u].w * g3;
+        }
+    }
+    if (acc == 123.456f) out[0] = acc;
+}
+
+template <int NTHR> void run_ldsdma(const char* name, const u32x4* idx, const f32x4* val, const float* table, size_t n16, float* out)
+{
+    const int grid = 512 * 512 / NTHR;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) k_sg_ldsdma<NTHR, 4><<<grid, NTHR>>>(idx, val, table, n16, out);
+    hipEventRecord(e0);
+    const int reps = 10;
+    for (int r = 0; r < reps; ++r) k_sg_ldsdma<NTHR, 4><<<grid, NTHR>>>(idx, val, table, n16, out);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    printf("%-34s wg %4d x %3d  4-byte gathers by LDS-DMA + ds_read, 4 per 4 items: %.3f ms  %6.1f G items/s\n", name, NTHR, grid, ms,
+           n16 * 4.0 / ms / 1e6);
+    fflush(stdout);
+}
+
 template <int NTHR, int GW, int NG> void run(const char* name, const u32x4* idx, const f32x4* val, const float* table, size_t n16, float* out)
 {
     const int grid = 512 * 512 / NTHR;
@@ -100,6 +147,7 @@ int main(int argc, char** argv)
         run<1024, 1, 4>(nm, (const u32x4*)idx, val, table, h16, out);
         run<1024, 4, 3>(nm, (const u32x4*)idx, val, table, h16, out);
         run<512, 4, 2>(nm, (const u32x4*)idx, val, table, h16, out);
+        run_ldsdma<512>(nm, (const u32x4*)idx, val, table, h16, out);
     }
     return 0;
 }
