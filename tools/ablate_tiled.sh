@@ -8,7 +8,7 @@
 #   PDLP_SELECT_SUM  PDLP_NO_SCAN2  PDLP_BURST_PRODUCTS  PDLP_COUNTS_AT_TOP  PDLP_COUNTS_THREAD_MAJOR  PDLP_CSR_BRANCHY
 #   PDLP_SLIDE=n  PDLP_NT_GATHER  PDLP_STAGGER=n  PDLP_STAMPS        (timing only, WRONG RESULTS:) PDLP_ABL_NOVAL  PDLP_ABL_NOCOUNTS  PDLP_ABL_NOGATHER
 # Tunables that need no patch (product sources): PDLP_PRIO_P1/_P2, PDLP_ROUND, PDLP_EPI_GROUP, PDLP_F32_RPT/_CAP/_TU, PDLP_TNT (threads per workgroup).
-# Round 5 (tools/experiments/r05_gather_lab.patch, applied by hand to a scratch copy): PDLP_GATHER_X4=1|2 (16-byte gathers), k_csr_fused<XLDS>.
+# Round 5 (tools/experiments/r05_gather_lab.patch, applied by hand to a scratch copy): PDLP_GATHER_X4=1|2 (16-byte gathers), PDLP_GATHER_LDSDMA=1, k_csr_fused<XLDS>.
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/_bin
