@@ -252,8 +252,13 @@ int pdlp_dual_half_piece(pdlp_handle h, int adaptive, int piece, int pieces);
  *                         PDLP_ERR_STATE when the handle cannot capture)
  *   PDLP_OPT_SPLIT_SLOTS  0 (default): the library's rule; local | other << 16: panel groups of a split product (tools/split_timing.py)
  *   PDLP_OPT_PRODUCER_PIECES 1 (default): with a chunked exchange the result of a split product leaves piece by piece
- *                         (pdlp_*_half_piece); 0: the half-step finishes before its block is exchanged (round-4 behaviour) */
-enum { PDLP_OPT_RUNNING_KKT = 0, PDLP_OPT_KTY_REUSE = 1, PDLP_OPT_GRAPH = 2, PDLP_OPT_SPLIT_SLOTS = 3, PDLP_OPT_PRODUCER_PIECES = 4 };
+ *                         (pdlp_*_half_piece); 0: the half-step finishes before its block is exchanged (round-4 behaviour)
+ *   PDLP_OPT_BEGIN_INLINE 0 (default): pdlp_*_half_begin multiply the local panels on a side stream of the library (forked from and
+ *                         joined to the handle's stream with events), so that they run beside a BLOCKING exchange on the handle's
+ *                         stream; 1: on the handle's stream itself -- for callers whose exchange is already under way on a stream of
+ *                         its own (an asynchronous collective): the same kernels without the two cross-stream dependencies */
+enum { PDLP_OPT_RUNNING_KKT = 0, PDLP_OPT_KTY_REUSE = 1, PDLP_OPT_GRAPH = 2, PDLP_OPT_SPLIT_SLOTS = 3, PDLP_OPT_PRODUCER_PIECES = 4,
+       PDLP_OPT_BEGIN_INLINE = 5 };
 int pdlp_set_option(pdlp_handle h, int option, int64_t value);
 int pdlp_exchange_plan(pdlp_handle h, int transpose, int32_t* nchunks, int64_t bounds[5]);
 int pdlp_half_chunk(pdlp_handle h, int transpose, int chunk);

@@ -65,6 +65,7 @@ class FakeComm:
         return Work(done)
 
     def all_gather(self, full): self._run(ag_ms).wait()
+    def all_gather_async(self, full): return self._run(ag_ms)
     def all_gather_piece(self, full, lo, hi):
         B = full.numel() // W
         return self._run(ag_ms * (hi - lo) / B) if hi > lo else None

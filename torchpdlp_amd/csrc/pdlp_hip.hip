@@ -222,6 +222,7 @@ struct Schedule {
     int loc_pa = 0, loc_pb = 0;
     int slotsA = 0, slotsB = 0;   // panel groups (= partial row sum slots) of the local and of all the other panels
     bool pending = false;         // the local panels of the next product are already in rowsum[0 .. slotsA)
+    bool pending_inline = false;  // ... and were launched on the handle's own stream (PDLP_OPT_BEGIN_INLINE): nothing to join
     // the exchange of the gathered vector in `nphase - 1` chunks (pdlp_set_exchange_chunks): chunk c moves elements
     // [sb[c], sb[c+1]) of EVERY rank's block; a panel belongs to the phase with which its last foreign entry arrives
     // (phase 0: the panels of the own block, phase 1 + c: chunk c).  ptab holds the panels phase by phase.
@@ -326,6 +327,7 @@ struct pdlp_solver {
     bool no_kty_reuse;            // PDLP_OPT_KTY_REUSE = 0: timing experiments
     int split_local, split_other; // PDLP_OPT_SPLIT_SLOTS: panel groups of a split product chosen by the caller (0: the library's rule)
     bool side_ok;                 // the library's own streams and events exist (graph replay, split products)
+    bool begin_inline;            // PDLP_OPT_BEGIN_INLINE: pdlp_*_half_begin launch on the handle's stream (the caller's exchange is asynchronous)
     bool producer_pieces;         // PDLP_OPT_PRODUCER_PIECES (default on): results of split products leave piece by piece (Schedule::nrange)
     // running products: K x (kxb[0]) is carried along by every dual half-step and both products are summed with the
     // average's weights (kx_sum, kty_sum), so a restart check evaluates K x_cur, K x_avg and K'y_avg WITHOUT products:
@@ -426,7 +428,7 @@ int launch_mat(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* 
     if (!h->use_split && (h->sK.pending || h->sKT.pending)) {
         // an early local-panel product that nobody is going to consume (the caller changed course): let it finish
         // before the row-sum scratch is reused
-        HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_out, 0));
+        if (!(h->sK.pending ? h->sK.pending_inline : h->sKT.pending_inline)) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_out, 0));
         h->sK.pending = h->sKT.pending = false;
         h->sK.chunks_done = h->sKT.chunks_done = 0;
     }
@@ -468,7 +470,7 @@ int launch_mat(pdlp_handle h, bool transpose, const void* vin, Epi epi, double* 
             for (int r = 0; r < r_from && R > 1; ++r) pofs += range_epi_grid(s, r, rows);
             for (int r = r_from; r < r_to && r < R; ++r) {
                 if (R > 1) launch_phase<T, TV>(h, s, rows, vin, h->stream, last, s.rb_lo[r], s.rb_lo[r + 1] - s.rb_lo[r]);
-                if (r == 0) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_out, 0));
+                if (r == 0 && !s.pending_inline) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_out, 0));
                 const int lo = R > 1 ? range_rows_lo(s, r) : 0, hi = R > 1 ? range_rows_hi(s, r, rows) : rows;
                 if (hi > lo)
                     hipLaunchKernelGGL((k_rowsum_epilogue<T, Epi>), dim3(grid_for(hi - lo)), dim3(BLOCK), 0, h->stream, (const T*)h->rowsum,
@@ -827,16 +829,23 @@ int configure_split(pdlp_handle h, bool transpose)
 template <typename T> int half_begin_t(pdlp_handle h, bool transpose, const void* vin)
 {
     Schedule& s = transpose ? h->sKT : h->sK;
-    if (!s.tiled || s.slotsA == 0 || !h->gstream || s.pending) return PDLP_OK;
+    if (!s.tiled || s.slotsA == 0 || (!h->gstream && !h->begin_inline) || s.pending) return PDLP_OK;
     const int rows = (int)(transpose ? h->nl : h->ml);
-    HIP_TRY(hipEventRecord(h->ev_in, h->stream));
-    HIP_TRY(hipStreamWaitEvent(h->gstream, h->ev_in, 0));
-    if (h->delta) launch_phase<float, float>(h, s, rows, transpose ? (const void*)h->gdy : (const void*)h->gdx, h->gstream, 0);
-    else if (std::is_same<T, double>::value && h->mixed) launch_phase<double, float>(h, s, rows, vin, h->gstream, 0);
-    else launch_phase<T, T>(h, s, rows, vin, h->gstream, 0);
-    HIP_TRY(hipEventRecord(h->ev_out, h->gstream));
+    // begin_inline (PDLP_OPT_BEGIN_INLINE): the caller has ALREADY issued the exchange asynchronously on a stream of its own, so the
+    // local panels simply go onto the handle's stream and run beside it -- no side stream, no fork / join events (each cross-stream
+    // dependency costs about a kernel launch on this stack); the half-step that follows then has nothing to wait for
+    hipStream_t st = h->begin_inline ? h->stream : h->gstream;
+    if (!h->begin_inline) {
+        HIP_TRY(hipEventRecord(h->ev_in, h->stream));
+        HIP_TRY(hipStreamWaitEvent(h->gstream, h->ev_in, 0));
+    }
+    if (h->delta) launch_phase<float, float>(h, s, rows, transpose ? (const void*)h->gdy : (const void*)h->gdx, st, 0);
+    else if (std::is_same<T, double>::value && h->mixed) launch_phase<double, float>(h, s, rows, vin, st, 0);
+    else launch_phase<T, T>(h, s, rows, vin, st, 0);
+    if (!h->begin_inline) HIP_TRY(hipEventRecord(h->ev_out, h->gstream));
     HIP_TRY(hipGetLastError());
     s.pending = true;
+    s.pending_inline = h->begin_inline;
     s.chunks_done = 0;
     return PDLP_OK;
 }
@@ -1401,7 +1410,7 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     h->kty_cur = -1;
     h->no_kty_reuse = false;
     h->split_local = h->split_other = 0;
-    h->producer_pieces = true;
+    h->producer_pieces = true; h->begin_inline = false;
     h->range_sel = -1; h->range_cnt = 1;
     h->rs_stride = (nl > ml ? nl : ml) + (int64_t)TNT * TRPT_MAX_ANY;
     h->rs_groups = (int)rowsum_groups(nl > ml ? nl : ml);
@@ -1674,6 +1683,7 @@ int pdlp_set_option(pdlp_handle h, int option, int64_t value)
             drop_graphs(h);
             h->graph_ok = value != 0 && h->side_ok && !h->comm;
             return (value != 0 && !h->graph_ok) ? PDLP_ERR_STATE : PDLP_OK;
+        case PDLP_OPT_BEGIN_INLINE: h->begin_inline = value != 0; return PDLP_OK;
         case PDLP_OPT_PRODUCER_PIECES: {
             h->producer_pieces = value != 0;
             drop_graphs(h);
@@ -1920,8 +1930,13 @@ int sharded_exchange_and_begin(pdlp_handle h, bool transpose, int adaptive, bool
     void* full = transpose ? (h->delta ? (void*)h->gdy : (void*)h->yb[h->ix_cur]) : (h->delta ? (void*)h->gdx : (void*)h->xbar);
     const int64_t block = transpose ? h->ml : h->nl;
     const bool f32 = h->delta || vec32;
-    // the panels that meet this rank's own block are multiplied (side stream) while the other blocks are on the wire
-    if (begin && (rc = (transpose ? pdlp_primal_half_begin(h) : pdlp_dual_half_begin(h, adaptive))) != PDLP_OK) return rc;
+    // the panels that meet this rank's own block are multiplied while the other blocks are on the wire: on the handle's own stream when
+    // the pieces are under way on the communication stream already, else on the side stream (the all-gather below is in stream order)
+    const bool saved_inline = h->begin_inline;
+    h->begin_inline = pieces_sent;
+    rc = begin ? (transpose ? pdlp_primal_half_begin(h) : pdlp_dual_half_begin(h, adaptive)) : PDLP_OK;
+    h->begin_inline = saved_inline;
+    if (rc != PDLP_OK) return rc;
     // (the shape of the exchange must not depend on anything rank local -- every rank issues the same collectives)
     int64_t sb[MAX_PHASE];
     const int C = plan_bounds(block, h->xchunks, sb);

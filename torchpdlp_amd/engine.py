@@ -46,6 +46,14 @@ class Comm:
         else:
             self.dist.all_gather_into_tensor(full, mine, group=self.group)
 
+    def all_gather_async(self, full: torch.Tensor):
+        """the same all-gather, not waited for: returns a handle whose ``wait()`` makes the current stream wait (None: already done)"""
+        if self.backend == "gloo" and full.is_cuda:
+            self.all_gather(full)
+            return None
+        shard = full.numel() // self.world
+        return self.dist.all_gather_into_tensor(full, full[self.rank * shard:(self.rank + 1) * shard], group=self.group, async_op=True)
+
     def all_gather_piece(self, full: torch.Tensor, lo: int, hi: int):
         """elements [lo, hi) of EVERY rank's block of ``full`` (this rank's are in place); returns a handle whose ``wait()`` makes the
         current stream wait for the piece (None: already there) -- the pieces of a chunked exchange queue up behind each other while
@@ -158,6 +166,10 @@ class PdlpEngine:
             self.set_option(N.OPT_RUNNING_KKT, 0)
         if os.environ.get("PDLP_NO_KTY_REUSE") is not None:
             self.set_option(N.OPT_KTY_REUSE, 0)
+        if self.comm is not None and os.environ.get("PDLP_BEGIN_INLINE", "1")[:1] != "0":
+            # the torch.distributed loop issues every exchange asynchronously BEFORE it starts the next product on the own block
+            # (iterate): the local panels then go onto the handle's stream, no side stream / events (pdlp_hip.h, PDLP_OPT_BEGIN_INLINE)
+            self.set_option(N.OPT_BEGIN_INLINE, 1)
         self.producer_pieces = os.environ.get("PDLP_PRODUCER_PIECES", "1")[:1] != "0"
         if not self.producer_pieces:
             self.set_option(N.OPT_PRODUCER_PIECES, 0)
@@ -553,6 +565,16 @@ class PdlpEngine:
             works.append(self.comm.all_gather_piece(full, lo, hi))
         return works
 
+    def _start_exchange(self, transpose: int, full: torch.Tensor, works):
+        """issue the exchange of ``full`` now, asynchronously, unless its pieces are on their way already; returns the handles
+        (a one-element list for a one-piece plan)"""
+        if works is not None:
+            return works
+        plan = self.exchange_plan(transpose)
+        if len(plan) == 1:
+            return [self.comm.all_gather_async(full)]
+        return [self.comm.all_gather_piece(full, lo, hi) for lo, hi in plan]
+
     def _exchange(self, transpose: int, full: torch.Tensor, works=None):
         """the input of the next product to every rank, in the pieces of its plan; the panels a piece completes are multiplied as
         soon as it is there (all but the last piece's: those belong to the half-step that follows).  ``works``: the pieces are
@@ -563,6 +585,10 @@ class PdlpEngine:
             return
         if works is None:
             works = [self.comm.all_gather_piece(full, lo, hi) for lo, hi in plan]
+        if len(plan) == 1:                       # (issued by _start_exchange)
+            if works[0] is not None:
+                works[0].wait()
+            return
         for c, w in enumerate(works):
             if w is not None:
                 w.wait()
@@ -668,8 +694,10 @@ class PdlpEngine:
             # With a chunked exchange the result of a half-step leaves piece by piece (_half_in_pieces): piece c's all-gather is
             # issued behind the rows it is made of and runs while the rows of piece c + 1 are still being multiplied.
             wx = self._half_in_pieces(False, a, xbar)
-            # the panels of K that meet this rank's own block of xbar are multiplied (side stream) while the
-            # other blocks are still on the wire; the same for K' and y below
+            # the panels of K that meet this rank's own block of xbar are multiplied while the other blocks are still on the wire
+            # (the exchange is issued first, asynchronously, so the panels go onto the handle's own stream: no fork / join); the
+            # same for K' and y below
+            wx = self._start_exchange(0, xbar, wx)
             N.check(lib.pdlp_dual_half_begin(h, a), "pdlp_dual_half_begin")
             self._exchange(0, xbar, wx)                    # K xbar needs every rank's block of xbar
             ynew = gdy if self.delta else self.buffer(N.BUF_Y_PREV)     # where the dual half-step writes (the buffers alternate)
@@ -682,11 +710,13 @@ class PdlpEngine:
                 N.check(lib.pdlp_adaptive_reduce(h), "pdlp_adaptive_reduce")
                 if wy is not None:
                     ar = comm.all_reduce_sum_async(red)
+            wy_sent = wy is not None
+            wy = self._start_exchange(1, ynew, wy)
             if it + 1 < iters:                             # (the new y is final: a rejected adaptive step is kept, quirk Q1)
                 N.check(lib.pdlp_primal_half_begin(h), "pdlp_primal_half_begin")
             self._exchange(1, ynew, wy)                    # (no product under way after the last iteration: the pieces just arrive)
             if adaptive:
-                if wy is None:
+                if not wy_sent:
                     comm.all_reduce_sum(red)
                 elif ar is not None:
                     ar.wait()
