@@ -256,12 +256,41 @@ int pdlp_dual_half_piece(pdlp_handle h, int adaptive, int piece, int pieces);
  *   PDLP_OPT_BEGIN_INLINE 0 (default): pdlp_*_half_begin multiply the local panels on a side stream of the library (forked from and
  *                         joined to the handle's stream with events), so that they run beside a BLOCKING exchange on the handle's
  *                         stream; 1: on the handle's stream itself -- for callers whose exchange is already under way on a stream of
- *                         its own (an asynchronous collective): the same kernels without the two cross-stream dependencies */
+ *                         its own (an asynchronous collective): the same kernels without the two cross-stream dependencies
+ *   PDLP_OPT_PEER_EXCHANGE 1 (default): a handle connected by pdlp_peer_connect iterates with the direct exchange; 0: with whatever it
+ *                         would use without (its RCCL communicator, or the caller's loop)
+ *   PDLP_OPT_PEER_TIMEOUT_MS how long a wait of the direct exchange spins before it gives up (default 10 000) */
 enum { PDLP_OPT_RUNNING_KKT = 0, PDLP_OPT_KTY_REUSE = 1, PDLP_OPT_GRAPH = 2, PDLP_OPT_SPLIT_SLOTS = 3, PDLP_OPT_PRODUCER_PIECES = 4,
-       PDLP_OPT_BEGIN_INLINE = 5 };
+       PDLP_OPT_BEGIN_INLINE = 5, PDLP_OPT_PEER_EXCHANGE = 6, PDLP_OPT_PEER_TIMEOUT_MS = 7 };
 int pdlp_set_option(pdlp_handle h, int option, int64_t value);
 int pdlp_exchange_plan(pdlp_handle h, int transpose, int32_t* nchunks, int64_t bounds[5]);
 int pdlp_half_chunk(pdlp_handle h, int transpose, int chunk);
+/* Direct exchange: the iterations of a sharded problem WITHOUT collectives (north_star: "sharded across the 8 GPUs of one node ...
+ * over xGMI"; SURVEY section 8e "hand-rolled P2P copies over xGMI with IPC buffers"; the reference has one device, PDLP/main.py:45-54).
+ * Every rank exports its workspace and a small mailbox over HIP IPC; once connected, the epilogue of a half-step stores its block of
+ * xbar / y (delta mode: of the float32 differences) into every peer's copy of that vector AS IT COMPUTES IT -- between GPUs these are
+ * xGMI stores that ride on the product, 35 MB per half-step and rank at 10M x 10M / 8 ranks against the 1 GB the product streams --, a
+ * one-wave kernel raises the rank's sequence number in the peers' mailboxes, and a one-wave kernel with a BOUNDED spin waits for the
+ * peers' numbers before the part of the next product that needs their blocks.  The step-size rule's three sums (step.py:85-96) travel
+ * with the flag of the y exchange and are added in rank order.  pdlp_iterate then is one call per restart period with no collective,
+ * no second stream and no event in it; everything outside the iterations (KKT sums, gathers for restart checks) stays with the caller.
+ *   pdlp_peer_export    this rank's PDLP_PEER_INFO_BYTES of connection data (IPC handles, offsets, shape); the caller distributes them
+ *                       (an all-gather of bytes over its process group).  The workspace must lie inside ONE device allocation.
+ *   pdlp_peer_connect   `infos` = the world x PDLP_PEER_INFO_BYTES bytes of all ranks in rank order (equal blocks, this rank's at
+ *                       rank * block; at most 8 ranks).  PDLP_ERR_INVALID: shapes disagree; PDLP_ERR_COMM: a handle would not open.
+ *                       flags = PDLP_PEER_LOOPBACK (infos may be null): a timing stand-in on ONE process -- the "peers" are scratch
+ *                       blocks, the flags land in the own mailbox (tools/shard_iter_timing.py); results are those of one rank alone.
+ *   pdlp_peer_status    out = { connected, enabled, 0 or 1 + the rank a wait gave up on, exchanges issued }.  A wait that gave up
+ *                       lets the stream run on with incomplete vectors: check after synchronising, before using any result.
+ *   pdlp_peer_close     unmaps the peers' memory, frees the mailbox (pdlp_destroy does the same).
+ * Identical bits to the other two drivers in fixed-step mode; in adaptive mode up to the order of the ranks' three sums (two ranks:
+ * identical).  Delta mode: the anchors must be valid on entry (PDLP_ERR_STATE otherwise: pdlp_refresh_products needs gathers). */
+#define PDLP_PEER_INFO_BYTES 256
+#define PDLP_PEER_LOOPBACK 1
+int pdlp_peer_export(pdlp_handle h, void* info);
+int pdlp_peer_connect(pdlp_handle h, int rank, int world, const void* infos, int flags);
+int pdlp_peer_status(pdlp_handle h, int32_t out[4]);
+int pdlp_peer_close(pdlp_handle h);
 int pdlp_comm_load(const char* rccl_path);
 int pdlp_comm_unique_id(const char* rccl_path, void* id128);
 int pdlp_comm_init(pdlp_handle h, const char* rccl_path, const void* id128, int rank, int nranks);

@@ -648,6 +648,150 @@ def test_library_exchange_equals_the_torch_distributed_loop(world, tiled):
         assert dict(ret) == {r: "ok" for r in range(world)}
 
 
+def _peer_worker(rank, world, port, ret, tiled):
+    """every sharded engine twice -- driven by the torch.distributed loop and by the direct exchange (pdlp_peer_*: the half-steps
+    store their blocks straight into the other ranks' workspaces over HIP IPC, flags in a mailbox, no collective in the iteration)
+    -- from the same state: same bits (the loop's all-reduce adds in rank order here, as the direct exchange does)"""
+    os.environ["PDLP_TILED"] = "1" if tiled else "0"
+    if tiled:
+        os.environ["PDLP_TILE_LW"] = "13"
+    import torchpdlp_amd as tp
+    from torchpdlp_amd import _native as N
+    from torchpdlp_amd.distributed import gather_solution, shard_engine
+    from torchpdlp_amd.solver import run_pdlp
+    _init(rank, world, port)
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        comm = _ordered_comm()
+        if tiled:
+            lp = gen_lp(330_000, 300_000, 4, seed=12, device=dev, recipe="mixed", dtype=torch.float64)
+        else:
+            lp = gen_lp(301, 403, 4, seed=21, recipe="mixed", ineq_frac=0.6, device=dev, dtype=torch.float64)
+        g = torch.Generator().manual_seed(3)
+        x0 = torch.randn(lp.n, generator=g, dtype=torch.float64).to(dev)
+        y0 = torch.randn(lp.m, generator=g, dtype=torch.float64).to(dev)
+        rough = torch.randn(lp.val.numel(), generator=g, dtype=torch.float64).to(dev) * 1e-9
+        configs = [("f32", torch.float32, None, False), ("mixed", torch.float32, torch.float64, False)]
+        if not tiled:
+            configs += [("f64", torch.float64, None, False), ("mixed+exact", torch.float64, torch.float64, True)]
+        n1, n2 = (9, 4) if not tiled else (3, 2)
+        for name, mat_dt, vec_dt, exact in configs:
+            vd = vec_dt or mat_dt
+            val = lp.val + rough if exact else lp.val
+            K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, val.to(mat_dt))
+            vecs = [t.to(vd) for t in (lp.c, lp.q, lp.l, lp.u)]
+
+            def mk():
+                if exact:
+                    return shard_engine(K.to(dtype=torch.float32), *vecs, lp.m_ineq, comm, vec_dtype=vd, exact=K)
+                return shard_engine(K, *vecs, lp.m_ineq, comm, vec_dtype=vec_dt)
+            eA, eB = mk(), mk()
+            assert eB.enable_peer_exchange(), (name, eB.peer_log)
+            st = eB.peer_status()
+            assert eB.peer_on and st["connected"] and st["enabled"] and st["gave_up_on"] is None and st["exchanges"] > 0, st
+            assert any("bit-identical" in s for s in eB.peer_log), eB.peer_log
+            assert not eA.peer_on and not eA.peer_status()["connected"]
+            if tiled:
+                assert all(t is not None for t in eB.tiles) and eB.split_info(0)["local_groups"] >= 1
+            for adaptive in (True, False):
+                outs = []
+                for e in (eA, eB):
+                    e.set_iterate(e.part.pad_cols(x0.to(vd))[e.cols[0]:e.cols[1]], e.part.pad_rows(y0.to(vd))[e.rows[0]:e.rows[1]])
+                    e.set_step(0.02, 1.1, 1.0, 0)
+                    before = e.peer_status()["exchanges"]
+                    e.iterate(n1, adaptive)
+                    e.iterate(n2, adaptive)
+                    x, y = e.get_iterate(N.CUR)
+                    outs.append((x.clone(), y.clone(), e.scalars()["eta"], e.kkt(N.CUR, 1.0)["kkt"]))
+                    # two exchanges per iteration and one entry handshake per call -- and none on the engine that was not connected
+                    assert e.peer_status()["exchanges"] - before == (2 * (n1 + n2) + 2 if e is eB else 0)
+                (xa, ya, ea, ka), (xb, yb, eb, kb) = outs
+                assert torch.equal(xa, xb) and torch.equal(ya, yb), (name, adaptive)
+                assert ea == eb and ka == kb, (name, adaptive, ea, eb, ka, kb)
+                assert bool(torch.isfinite(xa).all()) and float(xa.abs().sum()) > 0
+            if not tiled and name == "f32":
+                # a whole restarted solve: identical restart decisions, counters and solution on both drivers
+                sols = []
+                for e in (eA, eB):
+                    b0 = e.part.pad_cols(torch.randn(lp.n, generator=torch.Generator().manual_seed(9)).to(dev))
+                    tr = dict(kkt=[], omega=[], restarts=[])
+                    x, obj, k, n, j, st, _ = run_pdlp(e, tol=1e-4, verbose=False, primal_update=True, adaptive=True, b0=b0, trace=tr,
+                                                      max_kkt=300_000)
+                    sols.append((gather_solution(e, x, lp.n).cpu(), obj, k, n, j, st, tr["restarts"]))
+                assert sols[0][1:] == sols[1][1:] and torch.equal(sols[0][0], sols[1][0]), name
+                assert sols[0][5] == "Solved" and abs(sols[0][1] - lp.opt_obj) <= 2e-3 * (1 + abs(lp.opt_obj))
+            # switching the connected exchange off puts the engine back on the loop (same bits again), closing it disconnects
+            eB.set_peer_exchange(False)
+            eB.set_iterate(eB.part.pad_cols(x0.to(vd))[eB.cols[0]:eB.cols[1]], eB.part.pad_rows(y0.to(vd))[eB.rows[0]:eB.rows[1]])
+            eB.set_step(0.02, 1.1, 1.0, 0)
+            eB.iterate(n1, False)
+            eB.iterate(n2, False)
+            assert torch.equal(eB.get_iterate(N.CUR)[0], xb)
+            dist.barrier()                       # (nobody unmaps while a peer may still be storing)
+            eB.disable_peer_exchange()
+            assert not eB.peer_status()["connected"]
+            dist.barrier()
+            del eA, eB
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,tiled", [(2, False), (3, False), (2, True), (3, True)])
+def test_direct_exchange_equals_the_torch_distributed_loop(world, tiled):
+    """VERDICT r4 item 1c (SURVEY section 8e "hand-rolled P2P copies over xGMI with IPC buffers"): 2 and 3 ranks share the card, each
+    opens the others' workspaces over HIP IPC; f32, f64, mixed/delta (+ a separate exact matrix), adaptive and fixed step, plain
+    and split (tiled) products, a whole solve"""
+    port = _free_port()
+    with mp.Manager() as man:
+        ret = man.dict()
+        mp.spawn(_peer_worker, args=(world, port, ret, tiled), nprocs=world, join=True)
+        assert dict(ret) == {r: "ok" for r in range(world)}
+
+
+def _peer_timeout_worker(rank, world, port, ret):
+    import torchpdlp_amd as tp
+    from torchpdlp_amd import _native as N
+    from torchpdlp_amd.distributed import shard_engine
+    _init(rank, world, port)
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        comm = tp.Comm()
+        lp = gen_lp(301, 403, 4, seed=21, recipe="mixed", ineq_frac=0.6, device=dev, dtype=torch.float32)
+        K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
+        eng = shard_engine(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq, comm)
+        assert eng.enable_peer_exchange(cross_check=False, timeout_ms=200), eng.peer_log
+        eng.set_step(0.02, 1.0, 1.0, 0)
+        dist.barrier()
+        if rank == 0:                            # the other rank never comes: every wait gives up after 0.2 s, the grid drains
+            eng.iterate(1, False)
+            torch.cuda.synchronize()
+            assert eng.peer_status()["gave_up_on"] == 1
+            with pytest.raises(N.PdlpError, match="rank 1 did not signal"):
+                eng._peer_check()
+            with pytest.raises(N.PdlpError, match="did not signal"):
+                eng.iterate(1, False)
+        dist.barrier()
+        eng.disable_peer_exchange()
+        dist.barrier()
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_direct_exchange_wait_gives_up():
+    """a peer that never signals: the wait kernel's spin is bounded, the stream drains, and the host refuses to go on"""
+    port = _free_port()
+    with mp.Manager() as man:
+        ret = man.dict()
+        mp.spawn(_peer_timeout_worker, args=(2, port, ret), nprocs=2, join=True)
+        assert dict(ret) == {0: "ok", 1: "ok"}
+
+
 def _ruiz_worker(rank, world, port, ret):
     """sharded Ruiz: the scaled shards are the shards of the scaled matrix, bit for bit; then configs[4]'s combination
     (Ruiz + adaptive + primal weight, mixed precision) sharded over the ranks with no full copy anywhere"""

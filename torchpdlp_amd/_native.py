@@ -11,13 +11,14 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PDLP_LIB") or os.path.join(_HERE, "libpdlp_hip.so")   # PDLP_LIB: profiling/ablation builds (empty = unset)
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 PDLP_F32, PDLP_F64, PDLP_MIXED = 0, 1, 2
 CUR, AVG, PREV = 0, 1, 2
 (BUF_X_CUR, BUF_X_PREV, BUF_XBAR, BUF_X_AVG, BUF_Y_CUR, BUF_Y_PREV, BUF_Y_AVG, BUF_RED, BUF_X_SUM, BUF_Y_SUM,
  BUF_SCALARS, BUF_DX, BUF_DY, BUF_LAM_PREV, BUF_GDX, BUF_GDY) = range(16)
 NRED, NSCAL = 8, 16
-OPT_RUNNING_KKT, OPT_KTY_REUSE, OPT_GRAPH, OPT_SPLIT_SLOTS, OPT_PRODUCER_PIECES, OPT_BEGIN_INLINE = range(6)
+OPT_RUNNING_KKT, OPT_KTY_REUSE, OPT_GRAPH, OPT_SPLIT_SLOTS, OPT_PRODUCER_PIECES, OPT_BEGIN_INLINE, OPT_PEER_EXCHANGE, OPT_PEER_TIMEOUT_MS = range(8)
+PEER_INFO_BYTES, PEER_LOOPBACK = 256, 1
 # indices into the scalar block
 S_ETA, S_OMEGA, S_THETA, S_TAU, S_SIGMA, S_WPEND, S_ETASUM, S_K, S_INV1PT, S_ACCEPT, S_ETABAR, S_DEN, S_ETASUM_PREV = range(13)
 
@@ -78,6 +79,10 @@ SIGNATURES = {
     "pdlp_comm_load": (_I, [C.c_char_p]),
     "pdlp_comm_unique_id": (_I, [C.c_char_p, _P]),
     "pdlp_comm_init": (_I, [_H, C.c_char_p, _P, _I, _I]),
+    "pdlp_peer_export": (_I, [_H, _P]),
+    "pdlp_peer_connect": (_I, [_H, _I, _I, _P, _I]),
+    "pdlp_peer_status": (_I, [_H, C.POINTER(C.c_int32)]),
+    "pdlp_peer_close": (_I, [_H]),
     "pdlp_comm_all_gather": (_I, [_H, _I]),
     "pdlp_comm_all_reduce_red": (_I, [_H]),
     "pdlp_set_delta": (_I, [_H, _I]),

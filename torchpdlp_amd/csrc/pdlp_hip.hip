@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>      // types and prototypes only: the library is resolved with dlopen when a communicator is asked for
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <cmath>
 #include <cstdint>
@@ -37,6 +38,10 @@ constexpr int MAX_GRID = 2048;   // 256 CUs x 8 workgroups
 constexpr int NACC = 4;          // partial sums a kernel may produce
 constexpr int MAX_CHUNKS = 4;    // chunks of the exchange of a gathered vector (sharded problems)
 constexpr int MAX_PHASE = MAX_CHUNKS + 2;
+constexpr int MAX_PEER = 7;      // direct exchange (pdlp_peer_*): the other ranks of one node
+// a rank's mailbox for the direct exchange (fine-grained device memory, opened by every peer): the sequence number rank q last
+// signalled, one per 64-byte line, then rank q's three sums of the step-size rule
+constexpr int BOX_BYTES = 4096, BOX_FLAG_STRIDE = 16 /* uint32 */, BOX_SUMS_AT = 1024 /* bytes */, BOX_SUMS_STRIDE = 4 /* doubles */;
 
 // indices into the device scalar block (double[PDLP_NSCAL])
 enum { S_ETA = 0, S_OMEGA, S_THETA, S_TAU, S_SIGMA, S_WPEND, S_ETASUM, S_K, S_INV1PT, S_ACCEPT, S_ETABAR, S_DEN, S_ETASUM_PREV };
@@ -329,6 +334,27 @@ struct pdlp_solver {
     bool side_ok;                 // the library's own streams and events exist (graph replay, split products)
     bool begin_inline;            // PDLP_OPT_BEGIN_INLINE: pdlp_*_half_begin launch on the handle's stream (the caller's exchange is asynchronous)
     bool producer_pieces;         // PDLP_OPT_PRODUCER_PIECES (default on): results of split products leave piece by piece (Schedule::nrange)
+    char* ws;                     // the caller's workspace (pdlp_peer_export hands it to the other ranks)
+    int64_t ws_bytes;
+    // direct exchange (pdlp_peer_*): the other ranks' workspaces and mailboxes, opened over HIP IPC
+    struct Peer {
+        bool on = false;          // connected
+        bool enabled = true;      // PDLP_OPT_PEER_EXCHANGE: pdlp_iterate uses it
+        bool active = false;      // inside iterate_peer: the half-steps' epilogues store into the peers
+        bool loopback = false;    // timing stand-in: the "peers" are scratch buffers of this process
+        int rank = 0, world = 1, n = 0;      // n = world - 1 peers
+        void* opened[2 * MAX_PEER] = {};     // what hipIpcCloseMemHandle wants back
+        int nopened = 0;
+        char* out[6][MAX_PEER] = {};         // peer i's xbar, y buffers 0 / 1 / 2, gdx, gdy -- at THIS rank's block
+        uint32_t* flag[MAX_PEER] = {};       // this rank's slot in peer i's mailbox
+        double* sums[MAX_PEER] = {};
+        char* box = nullptr;                 // the own mailbox (fine-grained device memory)
+        char* scratch = nullptr;             // loopback: the stand-in destinations
+        int* err = nullptr;                  // host memory the wait kernel reports a timeout through
+        int* err_dev = nullptr;
+        uint32_t seq = 0;
+        long long limit_ticks = 1000000000LL;   // 10 s of the 100 MHz clock
+    } peer;
     // running products: K x (kxb[0]) is carried along by every dual half-step and both products are summed with the
     // average's weights (kx_sum, kty_sum), so a restart check evaluates K x_cur, K x_avg and K'y_avg WITHOUT products:
     // one product (K'y_cur, kept for the next primal half-step) instead of four per check
@@ -365,6 +391,18 @@ void drop_graphs(pdlp_handle h)
     }
 }
 
+// the direct exchange's mappings and allocations (the peers' memory is only unmapped here, never freed)
+void peer_release(pdlp_handle h)
+{
+    pdlp_solver::Peer& P = h->peer;
+    for (int i = 0; i < P.nopened; ++i) if (P.opened[i]) (void)hipIpcCloseMemHandle(P.opened[i]);
+    if (P.box) (void)hipFree(P.box);
+    if (P.scratch) (void)hipFree(P.scratch);
+    if (P.err) (void)hipHostFree(P.err);
+    (void)hipGetLastError();
+    P = pdlp_solver::Peer();
+}
+
 void free_handle(pdlp_handle h)
 {
     drop_graphs(h);
@@ -377,6 +415,7 @@ void free_handle(pdlp_handle h)
     if (h->ev_ar) (void)hipEventDestroy(h->ev_ar);
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->ev_out) (void)hipEventDestroy(h->ev_out);
+    peer_release(h);
     delete h;
 }
 
@@ -531,6 +570,15 @@ inline PieceCtl piece_ctl(pdlp_handle h, const Schedule& s, bool product_is_laun
     return PieceCtl{piece_mode && !capable && h->range_sel > 0, !piece_mode || h->range_sel >= h->range_cnt - 1};
 }
 
+// direct exchange: where the other ranks keep vector `v` (0 xbar, 1 / 2 / 3 the y buffers, 4 gdx, 5 gdy), at this rank's block
+template <typename T> void peer_targets(pdlp_handle h, PeerOut<T>& po, int v)
+{
+    po.n = 0;
+    if (!h->peer.active) return;
+    for (int i = 0; i < h->peer.n; ++i) po.p[i] = (T*)h->peer.out[v][i];
+    po.n = h->peer.n;
+}
+
 template <typename T> T* xloc(pdlp_handle h, int ix) { return (T*)h->xb[ix] + h->p.col0; }
 template <typename T> T* yloc(pdlp_handle h, int ix) { return (T*)h->yb[ix] + h->p.row0; }
 
@@ -559,6 +607,7 @@ template <typename T> int primal_half_t(pdlp_handle h, int adaptive)
     if (adaptive) {
         PrimalEpi<T, true> e{xloc<T>(h, h->ix_cur), xloc<T>(h, h->ix_prev), (T*)h->xbar + h->p.col0, (const T*)h->p.c,
                              (const T*)h->p.l, (const T*)h->p.u, (T*)h->x_sum, sc, ksum};
+        peer_targets(h, e.peer, 0);
         if (src >= 0) {
             h->last_gridA = h->nl > 0 ? grid_for(h->nl) : 0;
             return primal_from_kty<T>(h, src, e);
@@ -572,6 +621,7 @@ template <typename T> int primal_half_t(pdlp_handle h, int adaptive)
     }
     PrimalEpi<T, false> e{xloc<T>(h, h->ix_cur), xloc<T>(h, h->ix_prev), (T*)h->xbar + h->p.col0, (const T*)h->p.c,
                           (const T*)h->p.l, (const T*)h->p.u, (T*)h->x_sum, sc, ksum};
+    peer_targets(h, e.peer, 0);
     if (src >= 0) return primal_from_kty<T>(h, src, e);
     h->use_split = true;
     const int rc = launch_csr<T>(h, true, h->yb[h->ix_cur], e, h->partA);
@@ -600,12 +650,14 @@ template <typename T> int dual_half_t(pdlp_handle h, int adaptive)
     } else if (adaptive) {
         DualEpi<T, true> e{yloc<T>(h, h->ix_cur), yloc<T>(h, h->ix_prev), (const T*)h->p.q, (T*)h->y_sum, (T*)h->kxb[0],
                            h->sc, h->ineq_end, ksum};
+        peer_targets(h, e.peer, 1 + h->ix_prev);
         h->last_gridB = grid_of(h->sK, h->ml);
         h->use_split = true;
         rc = launch_csr<T>(h, false, h->xbar, e, h->partB);
     } else {
         DualEpi<T, false> e{yloc<T>(h, h->ix_cur), yloc<T>(h, h->ix_prev), (const T*)h->p.q, (T*)h->y_sum, (T*)h->kxb[0],
                             h->sc, h->ineq_end, ksum};
+        peer_targets(h, e.peer, 1 + h->ix_prev);
         h->use_split = true;
         rc = launch_csr<T>(h, false, h->xbar, e, h->partB);
     }
@@ -897,6 +949,7 @@ template <bool ADAPT> int delta_primal_half_a(pdlp_handle h)
     if (!h->anchors_valid && (rc = delta_refresh(h)) != PDLP_OK) return rc;
     DeltaPrimalEpi<ADAPT> e{(const double*)xloc<double>(h, h->ix_cur), xloc<double>(h, h->ix_prev), h->gdx + h->p.col0, (const double*)h->p.c,
                             (const double*)h->p.l, (const double*)h->p.u, (double*)h->x_sum, (double*)h->ktyr, h->sc};
+    peer_targets(h, e.peer, 4);
     if (h->dy_folded && !h->sKT.pending) {
         // K'y of the current y is already in the anchor (a restart check folded dy in, or the anchors are fresh): vector pass
         if (h->range_sel > 0) return PDLP_OK;                // (issued piece by piece: all of it went out with piece 0)
@@ -924,6 +977,7 @@ template <bool ADAPT> int delta_dual_half_a(pdlp_handle h)
 {
     DeltaDualEpi<ADAPT> e{(const double*)yloc<double>(h, h->ix_cur), yloc<double>(h, h->ix_prev), h->gdy + h->p.row0, (const double*)h->p.q,
                           (double*)h->y_sum, (double*)h->kxb[0], h->sc, h->ineq_end};
+    peer_targets(h, e.peer, 5);
     const PieceCtl pc = piece_ctl(h, h->sK);
     int rc = PDLP_OK;
     if (!pc.skip) {
@@ -1324,7 +1378,7 @@ int read_last_rowptr(const int64_t* rp, int64_t rows, int64_t* nnz, hipStream_t 
 // ================================================================================================
 extern "C" {
 
-int pdlp_abi_version(void) { return 16; }  // 16: pdlp_set_option (the library reads no environment variables), pdlp_mv_product, pdlp_mv_combine, pdlp_vec_sqdist, pdlp_probe_gather, pdlp_tile_limits reports the threads per workgroup, pdlp_primal_half_piece / pdlp_dual_half_piece (results of split products leave piece by piece), pdlp_trace_enable / pdlp_range_push / pdlp_range_pop (roctx), pdlp_adaptive_retry; 15: 64-bit row pointers, row-block bases of the tiles and schedule offsets (more than 2^31 non-zeros per handle); 14: pdlp_probe_stream_read; 13: chunked exchange (pdlp_set_exchange_chunks, pdlp_exchange_plan, pdlp_half_chunk); 12: count words of a tile laid out for coalesced loads; 11: pdlp_comm_load; 10: pdlp_set_anchors; 9: pdlp_attach_sorted; 8: running products, pdlp_flush_average(h, adaptive); 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
+int pdlp_abi_version(void) { return 17; }  // 17: pdlp_peer_* (direct exchange over HIP IPC), PDLP_OPT_BEGIN_INLINE; 16: pdlp_set_option (the library reads no environment variables), pdlp_mv_product, pdlp_mv_combine, pdlp_vec_sqdist, pdlp_probe_gather, pdlp_tile_limits reports the threads per workgroup, pdlp_primal_half_piece / pdlp_dual_half_piece (results of split products leave piece by piece), pdlp_trace_enable / pdlp_range_push / pdlp_range_pop (roctx), pdlp_adaptive_retry; 15: 64-bit row pointers, row-block bases of the tiles and schedule offsets (more than 2^31 non-zeros per handle); 14: pdlp_probe_stream_read; 13: chunked exchange (pdlp_set_exchange_chunks, pdlp_exchange_plan, pdlp_half_chunk); 12: count words of a tile laid out for coalesced loads; 11: pdlp_comm_load; 10: pdlp_set_anchors; 9: pdlp_attach_sorted; 8: running products, pdlp_flush_average(h, adaptive); 7: pdlp_comm_*; 6: remainder of a tiled matrix; 5: PDLP_MIXED, delta mode; 4: pdlp_tile_limits, pdlp_csr_div_cols takes nnz
 
 const char* pdlp_strerror(int code)
 {
@@ -1387,6 +1441,7 @@ int pdlp_create(pdlp_handle* out, const pdlp_problem* p, void* workspace, int64_
     int64_t ie = p->m_ineq - p->row0;
     h->ineq_end = (int)(ie < 0 ? 0 : (ie > ml ? ml : ie));
     char* w = (char*)workspace;
+    h->ws = w; h->ws_bytes = need;
     for (int i = 0; i < 3; ++i) h->xb[i] = w + offs[i];
     for (int i = 0; i < 3; ++i) h->yb[i] = w + offs[3 + i];
     h->ix_cur = 0; h->ix_prev = 1; h->ix_avg = 2;
@@ -1684,6 +1739,11 @@ int pdlp_set_option(pdlp_handle h, int option, int64_t value)
             h->graph_ok = value != 0 && h->side_ok && !h->comm;
             return (value != 0 && !h->graph_ok) ? PDLP_ERR_STATE : PDLP_OK;
         case PDLP_OPT_BEGIN_INLINE: h->begin_inline = value != 0; return PDLP_OK;
+        case PDLP_OPT_PEER_EXCHANGE: h->peer.enabled = value != 0; return PDLP_OK;
+        case PDLP_OPT_PEER_TIMEOUT_MS:
+            if (value < 1 || value > 3600000) return PDLP_ERR_INVALID;
+            h->peer.limit_ticks = (long long)value * 100000;            // (the wait kernel counts a 100 MHz clock)
+            return PDLP_OK;
         case PDLP_OPT_PRODUCER_PIECES: {
             h->producer_pieces = value != 0;
             drop_graphs(h);
@@ -2023,7 +2083,213 @@ int iterate_sharded(pdlp_handle h, int iters, int adaptive)
     return PDLP_OK;
 }
 
+// ---- direct exchange: no collective in the iteration -------------------------------------------------------------------------
+// "everything this rank has stored into your vectors up to now is complete" to every peer (and, with_sums, this rank's three sums of
+// the step-size rule): one tiny kernel behind the half-step that did the storing
+int peer_signal(pdlp_handle h, bool with_sums)
+{
+    pdlp_solver::Peer& P = h->peer;
+    PeerSignal sg{};
+    for (int i = 0; i < P.n; ++i) { sg.flag[i] = P.flag[i]; sg.sums[i] = P.sums[i]; }
+    sg.own_sums = (double*)(P.box + BOX_SUMS_AT) + (size_t)P.rank * BOX_SUMS_STRIDE;
+    sg.n = P.n;
+    sg.seq = ++P.seq;
+    hipLaunchKernelGGL(k_peer_signal, dim3(1), dim3(64), 0, h->stream, sg, with_sums ? (const double*)h->red : (const double*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return PDLP_OK;
+}
+
+// the handle's stream waits until every peer has signalled the exchange just signalled by this rank (bounded: k_peer_wait)
+int peer_wait(pdlp_handle h)
+{
+    pdlp_solver::Peer& P = h->peer;
+    hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, h->stream, (const uint32_t*)P.box, P.world, P.rank, P.seq, P.limit_ticks, P.err_dev);
+    HIP_TRY(hipGetLastError());
+    return PDLP_OK;
+}
+
+// The iterations of a sharded problem WITHOUT collectives: a half-step's epilogue stores its block of xbar / y (delta mode: of the
+// float32 differences) into every peer's copy as it computes it (PeerOut), a one-wave kernel raises this rank's flag in the peers'
+// mailboxes, the panels of the next product that meet the own block are multiplied, a one-wave kernel waits for the peers' flags,
+// and the rest of the product follows.  The step-size rule's three sums travel with the flag of the y exchange and are added in rank
+// order by every rank.  One stream, no events; per half-step the exchange adds two launches of a few microseconds to the critical
+// path (tools/src/ipc_probe.hip: 5.8 us for the pair between two processes) where an all-gather adds its whole duration.
+// Same arithmetic as iterate_sharded / PdlpEngine.iterate: identical bits in fixed-step mode; in adaptive mode up to the order in
+// which the ranks' sums are added (rank order here, the collective's order there; two ranks: identical).
+int iterate_peer(pdlp_handle h, int iters, int adaptive)
+{
+    int rc = PDLP_OK;
+    pdlp_solver::Peer& P = h->peer;
+    if (h->delta && iters > 0 && !h->anchors_valid) return PDLP_ERR_STATE;       // (the caller refreshes the anchors: that needs gathers)
+    if (iters == 0) return PDLP_OK;
+    const bool f32 = h->p.dtype == PDLP_F32;
+    // entry handshake: a peer's first block may only arrive once this rank's stream has reached the iterations -- whatever this rank
+    // did with its vectors before (a restart check, a restart) is behind the flag
+    if ((rc = peer_signal(h, false)) != PDLP_OK || (rc = peer_wait(h)) != PDLP_OK) return rc;
+    const bool saved_inline = h->begin_inline;
+    h->begin_inline = true;                       // (nothing runs beside the handle's stream: the own-block panels go onto it)
+    P.active = true;
+    for (int it = 0; it < iters && rc == PDLP_OK; ++it) {
+        if ((rc = pdlp_primal_half(h, adaptive)) != PDLP_OK) break;              // stores xbar (x+ - x) into the peers
+        if ((rc = peer_signal(h, false)) != PDLP_OK) break;
+        if ((rc = pdlp_dual_half_begin(h, adaptive)) != PDLP_OK) break;          // K's panels over the own block of xbar
+        if ((rc = peer_wait(h)) != PDLP_OK) break;
+        if ((rc = pdlp_dual_half(h, adaptive)) != PDLP_OK) break;                // stores the new y (y+ - y) into the peers
+        if (adaptive && (rc = pdlp_adaptive_reduce(h)) != PDLP_OK) break;        // this rank's three sums -> red
+        if ((rc = peer_signal(h, adaptive != 0)) != PDLP_OK) break;
+        if (it + 1 < iters && (rc = pdlp_primal_half_begin(h)) != PDLP_OK) break;
+        if ((rc = peer_wait(h)) != PDLP_OK) break;
+        if (adaptive) {
+            const double* sums = (const double*)(P.box + BOX_SUMS_AT);
+            if (f32) hipLaunchKernelGGL(k_adaptive_update_peer<float>, dim3(1), dim3(1), 0, h->stream, h->sc, h->red, sums, P.world);
+            else hipLaunchKernelGGL(k_adaptive_update_peer<double>, dim3(1), dim3(1), 0, h->stream, h->sc, h->red, sums, P.world);
+        }
+    }
+    P.active = false;
+    h->begin_inline = saved_inline;
+    if (rc != PDLP_OK) return rc;
+    HIP_TRY(hipGetLastError());
+    if (!adaptive) return pdlp_fixed_advance(h, iters);
+    return PDLP_OK;
+}
+
+// what a rank tells the others (pdlp_peer_export): PDLP_PEER_INFO_BYTES opaque bytes
+struct PeerInfo {
+    uint32_t magic, version;
+    hipIpcMemHandle_t ws, box;
+    int64_t ws_off;                 // the workspace inside its allocation (an IPC handle opens at the allocation's base)
+    int64_t vec_off[6];             // xbar, the three y buffers, gdx, gdy inside the workspace
+    int64_t n, m, nl, ml;
+    int32_t dtype, pid;
+};
+static_assert(sizeof(PeerInfo) <= PDLP_PEER_INFO_BYTES, "PeerInfo must fit its published size");
+constexpr uint32_t PEER_MAGIC = 0x50444c50u;
+
+void peer_vec_offsets(pdlp_handle h, int64_t off[6])
+{
+    off[0] = h->xbar - h->ws;
+    for (int i = 0; i < 3; ++i) off[1 + i] = h->yb[i] - h->ws;
+    off[4] = (char*)h->gdx - h->ws;
+    off[5] = (char*)h->gdy - h->ws;
+}
+
+// bytes per element of target vector v and the start of this rank's block in it
+size_t peer_block_start(pdlp_handle h, int v)
+{
+    const size_t esz = v >= 4 ? 4 : h->es;
+    return (size_t)(v == 0 || v == 4 ? h->p.col0 : h->p.row0) * esz;
+}
+
+int peer_own_resources(pdlp_handle h)
+{
+    pdlp_solver::Peer& P = h->peer;
+    if (!P.box) {
+        HIP_TRY(hipExtMallocWithFlags((void**)&P.box, BOX_BYTES, hipDeviceMallocFinegrained));
+        HIP_TRY(hipMemsetAsync(P.box, 0, BOX_BYTES, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    if (!P.err) {
+        HIP_TRY(hipHostMalloc((void**)&P.err, 64, hipHostMallocMapped));
+        *P.err = 0;
+        HIP_TRY(hipHostGetDevicePointer((void**)&P.err_dev, P.err, 0));
+    }
+    return PDLP_OK;
+}
+
 }  // namespace
+
+int pdlp_peer_export(pdlp_handle h, void* info)
+{
+    if (!h || !info) return PDLP_ERR_INVALID;
+    if (h->nl == h->p.n && h->ml == h->p.m) return PDLP_ERR_STATE;              // not sharded: nothing to exchange
+    HIP_TRY(hipSetDevice(h->p.device));
+    int rc;
+    if ((rc = peer_own_resources(h)) != PDLP_OK) return rc;
+    PeerInfo pi{};
+    pi.magic = PEER_MAGIC; pi.version = (uint32_t)pdlp_abi_version();
+    hipDeviceptr_t base = nullptr;
+    size_t range = 0;
+    HIP_TRY(hipMemGetAddressRange(&base, &range, (hipDeviceptr_t)h->ws));
+    if ((char*)h->ws + h->ws_bytes > (char*)base + range) return PDLP_ERR_WORKSPACE;   // (a workspace spanning allocations cannot be exported)
+    HIP_TRY(hipIpcGetMemHandle(&pi.ws, (void*)base));
+    HIP_TRY(hipIpcGetMemHandle(&pi.box, (void*)h->peer.box));
+    pi.ws_off = h->ws - (char*)base;
+    peer_vec_offsets(h, pi.vec_off);
+    pi.n = h->p.n; pi.m = h->p.m; pi.nl = h->nl; pi.ml = h->ml;
+    pi.dtype = h->p.dtype; pi.pid = (int32_t)getpid();
+    std::memset(info, 0, PDLP_PEER_INFO_BYTES);
+    std::memcpy(info, &pi, sizeof pi);
+    return PDLP_OK;
+}
+
+int pdlp_peer_connect(pdlp_handle h, int rank, int world, const void* infos, int flags)
+{
+    if (!h || world < 2 || world > MAX_PEER + 1 || rank < 0 || rank >= world) return PDLP_ERR_INVALID;
+    if (h->nl * world != h->p.n || h->ml * world != h->p.m || h->p.col0 != (int64_t)rank * h->nl || h->p.row0 != (int64_t)rank * h->ml)
+        return PDLP_ERR_INVALID;                   // equal blocks, this rank's at rank * block (torchpdlp_amd/distributed.py)
+    const bool loopback = (flags & PDLP_PEER_LOOPBACK) != 0;
+    if (!loopback && !infos) return PDLP_ERR_INVALID;
+    HIP_TRY(hipSetDevice(h->p.device));
+    pdlp_solver::Peer& P = h->peer;
+    if (P.on) return PDLP_ERR_STATE;
+    int rc;
+    if ((rc = peer_own_resources(h)) != PDLP_OK) return rc;
+    P.rank = rank; P.world = world; P.n = 0; P.loopback = loopback;
+    if (loopback) {
+        // timing stand-in (tools/shard_iter_timing.py): rank `rank` of `world` alone -- every "peer vector" is a scratch block of this
+        // process, every flag lands in the own mailbox (the waits pass at once).  What it prices: the stores and the two launches.
+        const size_t blk = (size_t)(h->nl > h->ml ? h->nl : h->ml) * 8;
+        HIP_TRY(hipMalloc((void**)&P.scratch, blk * (size_t)(world - 1)));
+        for (int q = 0, i = 0; q < world; ++q) {
+            if (q == rank) continue;
+            for (int v = 0; v < 6; ++v) P.out[v][i] = P.scratch + blk * (size_t)i;
+            P.flag[i] = (uint32_t*)P.box + (size_t)q * BOX_FLAG_STRIDE;
+            P.sums[i] = (double*)(P.box + BOX_SUMS_AT) + (size_t)q * BOX_SUMS_STRIDE;
+            ++i;
+            P.n = i;
+        }
+        P.on = true;
+        return PDLP_OK;
+    }
+    int64_t mine[6];
+    peer_vec_offsets(h, mine);
+    for (int q = 0, i = 0; q < world; ++q) {
+        if (q == rank) continue;
+        PeerInfo pi;
+        std::memcpy(&pi, (const char*)infos + (size_t)q * PDLP_PEER_INFO_BYTES, sizeof pi);
+        if (pi.magic != PEER_MAGIC || pi.version != (uint32_t)pdlp_abi_version() || pi.n != h->p.n || pi.m != h->p.m || pi.nl != h->nl ||
+            pi.ml != h->ml || pi.dtype != h->p.dtype) { peer_release(h); return PDLP_ERR_INVALID; }
+        char *wsb = nullptr, *box = nullptr;
+        if (hipIpcOpenMemHandle((void**)&wsb, pi.ws, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); peer_release(h); return PDLP_ERR_COMM; }
+        P.opened[P.nopened++] = wsb;
+        if (hipIpcOpenMemHandle((void**)&box, pi.box, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); peer_release(h); return PDLP_ERR_COMM; }
+        P.opened[P.nopened++] = box;
+        for (int v = 0; v < 6; ++v) P.out[v][i] = wsb + pi.ws_off + pi.vec_off[v] + peer_block_start(h, v);
+        P.flag[i] = (uint32_t*)box + (size_t)rank * BOX_FLAG_STRIDE;
+        P.sums[i] = (double*)(box + BOX_SUMS_AT) + (size_t)rank * BOX_SUMS_STRIDE;
+        ++i;
+        P.n = i;
+    }
+    P.on = true;
+    return PDLP_OK;
+}
+
+int pdlp_peer_status(pdlp_handle h, int32_t out[4])
+{
+    if (!h || !out) return PDLP_ERR_INVALID;
+    out[0] = h->peer.on; out[1] = h->peer.enabled;
+    out[2] = h->peer.err ? __atomic_load_n(h->peer.err, __ATOMIC_RELAXED) : 0;
+    out[3] = (int32_t)h->peer.seq;
+    return PDLP_OK;
+}
+
+int pdlp_peer_close(pdlp_handle h)
+{
+    if (!h) return PDLP_ERR_INVALID;
+    (void)hipStreamSynchronize(h->stream);
+    peer_release(h);
+    return PDLP_OK;
+}
 
 int pdlp_comm_load(const char* rccl_path) { return rccl_load(rccl_path); }
 
@@ -2090,6 +2356,7 @@ int pdlp_iterate(pdlp_handle h, int iters, int adaptive)
     char rname[64];
     if (g_roctx.level > 0) std::snprintf(rname, sizeof rname, "pdlp: %d %s iterations", iters, adaptive ? "adaptive" : "fixed-step");
     Range range(rname, h->stream);
+    if (h->peer.on && h->peer.enabled) return iterate_peer(h, iters, adaptive);
     if (h->comm) return iterate_sharded(h, iters, adaptive);
     if (h->nl != h->p.n || h->ml != h->p.m) return PDLP_ERR_STATE;   // sharded without a communicator: the caller does the exchange
     int rc, left = iters;

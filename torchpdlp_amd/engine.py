@@ -192,6 +192,7 @@ class PdlpEngine:
         # the exchange inside the library (one C call per restart period) is opt-in: PDLP_LIB_COMM=1 here, or
         # enable_library_comm() by the caller (bench.py does); the default is the torch.distributed loop of iterate()
         self.lib_comm, self.lib_comm_log = False, []
+        self.peer_on, self.peer_log = False, []          # direct exchange over HIP IPC (enable_peer_exchange)
         if self.comm is not None and self.comm.backend == "nccl" and tiles and os.environ.get("PDLP_LIB_COMM", "0") == "1":
             self.enable_library_comm()
 
@@ -435,11 +436,125 @@ class PdlpEngine:
         self.lib_comm = True
         return True
 
+    # ---- direct exchange (pdlp_peer_*): iterations without collectives ------------------------------------------------------
+    def enable_peer_exchange(self, cross_check: bool = True, timeout_ms: Optional[int] = None) -> bool:
+        """Connect the ranks' handles over HIP IPC (``pdlp_peer_export`` / ``pdlp_peer_connect``, include/pdlp_hip.h): ``iterate`` then
+        is ONE library call per restart period with NO collective in it -- every half-step stores its block of the exchanged vector
+        straight into the other ranks' memory (xGMI between the GPUs of a node) and a flag follows; the step-size rule's sums travel
+        with the flag.  At most 8 ranks, all on one node.  Every step is agreed on by all ranks over the process group: export,
+        connect, and (``cross_check``) two fixed-step iterations that must equal the torch.distributed loop bit for bit plus two
+        adaptive ones that must agree to 1e-5 (the ranks' three sums are added in rank order here, in the collective's order there;
+        identical for two ranks).  Any failure leaves all ranks where they were.  Call before the iterate is set (the cross-check
+        overwrites it and resets it to zero).  ``self.peer_log`` records what happened.  Returns whether the direct exchange is on."""
+        if self.comm is None or not hasattr(self.comm, "dist"):
+            return False
+        dist, group = self.comm.dist, self.comm.group
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        log = self.peer_log = []
+        host_coll = dist.get_backend(group) == "gloo"
+        cdev = "cpu" if host_coll else self.device
+
+        def agree(ok) -> int:                                    # MIN over the ranks
+            flag = torch.tensor([int(bool(ok))], dtype=torch.int32, device=cdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            return int(flag)
+
+        if not agree(2 <= world <= 8):
+            log.append(f"{world} ranks: the direct exchange connects 2 to 8")
+            return False
+        nb = N.PEER_INFO_BYTES
+        info = (C.c_char * nb)()
+        rc = self.lib.pdlp_peer_export(self.h, info)
+        mine = torch.tensor(list(info.raw) + [int(rc == 0)], dtype=torch.uint8, device=cdev)
+        every = torch.empty(world * (nb + 1), dtype=torch.uint8, device=cdev)
+        dist.all_gather_into_tensor(every, mine, group=group)
+        raw = bytes(every.cpu().tolist())
+        if not all(raw[q * (nb + 1) + nb] for q in range(world)):
+            log.append(f"export failed on some rank (this rank: rc={rc})")
+            return False
+        infos = b"".join(raw[q * (nb + 1):q * (nb + 1) + nb] for q in range(world))
+        rc = self.lib.pdlp_peer_connect(self.h, rank, world, infos, 0)
+        if not agree(rc == 0):
+            log.append(f"connect failed on some rank (this rank: rc={rc})")
+            if rc == 0:
+                self.lib.pdlp_peer_close(self.h)
+            return False
+        if timeout_ms is not None:
+            self.set_option(N.OPT_PEER_TIMEOUT_MS, int(timeout_ms))
+        self.peer_on = True
+        self.set_option(N.OPT_PEER_EXCHANGE, 1)
+        if cross_check:
+            try:
+                same = int(self._cross_check_peer())
+            except N.PdlpError as e:
+                log.append(f"cross-check raised: {e}")
+                same = 0
+            if not agree(same):
+                log.append("cross-check against the torch.distributed loop differs")
+                self.disable_peer_exchange()
+                return False
+            log.append("cross-check: 2 fixed-step iterations bit-identical, 2 adaptive ones within 1e-5 of the torch.distributed loop")
+        return True
+
+    def disable_peer_exchange(self):
+        self.peer_on = False
+        N.check(self.lib.pdlp_peer_close(self.h), "pdlp_peer_close")
+
+    def set_peer_exchange(self, on: bool):
+        """use (or not) a connected direct exchange for the iterations"""
+        st = self.peer_status()
+        self.peer_on = bool(on) and st["connected"]
+        self.set_option(N.OPT_PEER_EXCHANGE, int(self.peer_on))
+
+    def peer_status(self) -> dict:
+        out = (C.c_int32 * 4)()
+        N.check(self.lib.pdlp_peer_status(self.h, out), "pdlp_peer_status")
+        return dict(connected=bool(out[0]), enabled=bool(out[1]), gave_up_on=(out[2] - 1 if out[2] else None), exchanges=out[3])
+
+    def _peer_check(self):
+        """a wait of the direct exchange that gave up leaves incomplete vectors behind: never compute on"""
+        if self.peer_on:
+            st = self.peer_status()
+            if st["gave_up_on"] is not None:
+                raise N.PdlpError(f"direct exchange: rank {st['gave_up_on']} did not signal within the timeout "
+                                  f"(exchange {st['exchanges']}); the iterate of this rank is incomplete")
+
+    def _cross_check_peer(self, iters: int = 2, eta: float = 1e-2) -> bool:
+        zeros = lambda ln: torch.zeros(ln, dtype=self.dtype, device=self.device)
+        ok = True
+        saved_lib = self.lib_comm
+        self.lib_comm = False
+        for adaptive in (False, True):
+            out = []
+            for peer in (False, True):
+                self.set_peer_exchange(peer)
+                self.set_iterate(zeros(self.nl), zeros(self.ml))
+                self.set_step(eta, 1.0, 1.0, 0)
+                self.iterate(iters, adaptive)
+                x, y = self.get_iterate(N.CUR)         # (synchronises)
+                self._peer_check()
+                out.append((x, y, self.scalars()["eta"]))
+            (x0, y0, e0), (x1, y1, e1) = out
+            fin = bool(torch.isfinite(x1).all()) and bool(torch.isfinite(y1).all())
+            if adaptive and self.comm.world > 2:
+                close = lambda a, b: bool(((a - b).abs() <= 1e-5 * (1 + b.abs())).all())
+                ok = ok and fin and close(x1, x0) and close(y1, y0) and abs(e1 - e0) <= 1e-5 * abs(e0)
+            else:
+                ok = ok and fin and torch.equal(x0, x1) and torch.equal(y0, y1) and e0 == e1
+        self.lib_comm = saved_lib
+        self.set_peer_exchange(True)
+        self.set_iterate(zeros(self.nl), zeros(self.ml))
+        self.set_step(0.0, 1.0, 1.0, 0)
+        return bool(ok)
+
     def _cross_check_paths(self, iters: int = 2, eta: float = 1e-2) -> bool:
         """`iters` adaptive iterations from x = y = 0 through the torch.distributed loop and through the library's own
         exchange: the same bits on this rank?  Leaves the engine at x = y = 0, eta = 0 (a fresh handle's state)."""
         zeros = lambda ln: torch.zeros(ln, dtype=self.dtype, device=self.device)
         out = []
+        saved_peer = self.peer_on
+        if saved_peer:
+            self.set_peer_exchange(False)
         for lib in (False, True):
             self.lib_comm = lib
             self.set_iterate(zeros(self.nl), zeros(self.ml))
@@ -448,6 +563,8 @@ class PdlpEngine:
             x, y = self.get_iterate(N.CUR)
             out.append((x, y, self.scalars()["eta"]))
         self.lib_comm = False
+        if saved_peer:
+            self.set_peer_exchange(True)
         self.set_iterate(zeros(self.nl), zeros(self.ml))
         self.set_step(0.0, 1.0, 1.0, 0)
         (x0, y0, e0), (x1, y1, e1) = out
@@ -677,6 +794,12 @@ class PdlpEngine:
         """`iters` PDHG iterations, no host synchronisation (pdhg.py:76-112)."""
         if self.exact is not None and self.delta and int(iters) > 0 and not self.delta_state()["anchors_valid"]:
             self.refresh_products()
+        if self.peer_on:                            # direct exchange: one call, no collective (the anchors of delta mode need gathers)
+            self._peer_check()
+            if self.delta and int(iters) > 0 and not self.delta_state()["anchors_valid"]:
+                self.refresh_products()
+            N.check(self.lib.pdlp_iterate(self.h, int(iters), int(adaptive)), "pdlp_iterate")
+            return
         if self.comm is None or self.lib_comm:      # single GPU, or the exchange runs inside the library (RCCL)
             N.check(self.lib.pdlp_iterate(self.h, int(iters), int(adaptive)), "pdlp_iterate")
             return
@@ -758,6 +881,7 @@ class PdlpEngine:
             self.comm.all_reduce_sum(self.buffer(N.BUF_RED))
         out = (C.c_double * 6)()
         N.check(self.lib.pdlp_kkt_finish(self.h, float(omega), out), "pdlp_kkt_finish")
+        self._peer_check()                       # (the stream has been synchronised: a wait that gave up shows now)
         return dict(pr=out[0], dr=out[1], gap=out[2], p=out[3], d_adj=out[4], kkt=out[5])
 
     def restart(self, which: int):
