@@ -259,9 +259,12 @@ int pdlp_dual_half_piece(pdlp_handle h, int adaptive, int piece, int pieces);
  *                         its own (an asynchronous collective): the same kernels without the two cross-stream dependencies
  *   PDLP_OPT_PEER_EXCHANGE 1 (default): a handle connected by pdlp_peer_connect iterates with the direct exchange; 0: with whatever it
  *                         would use without (its RCCL communicator, or the caller's loop)
- *   PDLP_OPT_PEER_TIMEOUT_MS how long a wait of the direct exchange spins before it gives up (default 10 000) */
+ *   PDLP_OPT_PEER_TIMEOUT_MS how long a wait of the direct exchange spins before it gives up (default 10 000)
+ *   PDLP_OPT_PEER_LOCAL_FIRST 0 (default): direct exchange = signal, wait, the whole product; 1: the product is split and the panels that
+ *                         meet the own block run between signal and wait (they hide ranks finishing at different times but cannot
+ *                         fill the chip: 1/world of the panels) -- same sums up to the grouping of the partial row sums */
 enum { PDLP_OPT_RUNNING_KKT = 0, PDLP_OPT_KTY_REUSE = 1, PDLP_OPT_GRAPH = 2, PDLP_OPT_SPLIT_SLOTS = 3, PDLP_OPT_PRODUCER_PIECES = 4,
-       PDLP_OPT_BEGIN_INLINE = 5, PDLP_OPT_PEER_EXCHANGE = 6, PDLP_OPT_PEER_TIMEOUT_MS = 7 };
+       PDLP_OPT_BEGIN_INLINE = 5, PDLP_OPT_PEER_EXCHANGE = 6, PDLP_OPT_PEER_TIMEOUT_MS = 7, PDLP_OPT_PEER_LOCAL_FIRST = 8 };
 int pdlp_set_option(pdlp_handle h, int option, int64_t value);
 int pdlp_exchange_plan(pdlp_handle h, int transpose, int32_t* nchunks, int64_t bounds[5]);
 int pdlp_half_chunk(pdlp_handle h, int transpose, int chunk);

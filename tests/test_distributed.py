@@ -687,7 +687,7 @@ def _peer_worker(rank, world, port, ret, tiled):
                     return shard_engine(K.to(dtype=torch.float32), *vecs, lp.m_ineq, comm, vec_dtype=vd, exact=K)
                 return shard_engine(K, *vecs, lp.m_ineq, comm, vec_dtype=vec_dt)
             eA, eB = mk(), mk()
-            assert eB.enable_peer_exchange(), (name, eB.peer_log)
+            assert eB.enable_peer_exchange(local_first=True), (name, eB.peer_log)
             st = eB.peer_status()
             assert eB.peer_on and st["connected"] and st["enabled"] and st["gave_up_on"] is None and st["exchanges"] > 0, st
             assert any("bit-identical" in s for s in eB.peer_log), eB.peer_log
@@ -710,6 +710,21 @@ def _peer_worker(rank, world, port, ret, tiled):
                 assert torch.equal(xa, xb) and torch.equal(ya, yb), (name, adaptive)
                 assert ea == eb and ka == kb, (name, adaptive, ea, eb, ka, kb)
                 assert bool(torch.isfinite(xa).all()) and float(xa.abs().sum()) > 0
+            # the default form of the direct exchange -- signal, wait, the WHOLE product: unsplit products, so for tiles the partial row
+            # sums are grouped differently (CSR: the same bits again)
+            eB.set_peer_local_first(False)
+            eB.set_iterate(eB.part.pad_cols(x0.to(vd))[eB.cols[0]:eB.cols[1]], eB.part.pad_rows(y0.to(vd))[eB.rows[0]:eB.rows[1]])
+            eB.set_step(0.02, 1.1, 1.0, 0)
+            eB.iterate(n1, False)
+            eB.iterate(n2, False)
+            xw, yw = eB.get_iterate(N.CUR)
+            eB._peer_check()
+            if tiled:
+                tol = 2e-4 if name == "f32" else 2e-5
+                np.testing.assert_allclose(xw.cpu().numpy(), xb.cpu().numpy(), rtol=tol, atol=tol)
+                np.testing.assert_allclose(yw.cpu().numpy(), yb.cpu().numpy(), rtol=tol, atol=tol)
+            else:
+                assert torch.equal(xw, xb) and torch.equal(yw, yb), name
             if not tiled and name == "f32":
                 # a whole restarted solve: identical restart decisions, counters and solution on both drivers
                 sols = []

@@ -8,7 +8,10 @@ piece, at once for a blocking collective).  What it measures: the critical path 
 exchange the products hide -- the source of DESIGN.md section 5's ESTIMATE.  NOT a scaling measurement: no second GPU, no RCCL kernels
 competing for CUs and HBM.
 env: WORLD (8), AG_MS (0.1) or AG_LIST ("0.1,0.2"), AR_MS (0.02), CHUNKS ("1,2"), N (10M), K (100), ITERS (40), ADAPTIVE (1),
-DTYPE (f32 | mixed), PDLP_PRODUCER_PIECES (0: a half-step finishes before its block is exchanged, the round-4 behaviour)"""
+DTYPE (f32 | mixed), PDLP_PRODUCER_PIECES (0: a half-step finishes before its block is exchanged, the round-4 behaviour),
+PEER (1: also the direct exchange in loopback -- pdlp_peer_connect(PDLP_PEER_LOOPBACK): the epilogues store the block into WORLD - 1
+scratch blocks of this GPU instead of into peers over xGMI, the flags land in the own mailbox so the waits pass at once: what is
+priced is the stores, the two one-wave launches per exchange and the single-stream structure -- not the skew between real ranks)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["PDLP_TILED"] = "1"
@@ -115,6 +118,23 @@ def products_alone():
 
 
 print(f"   products alone (2 half-steps, no exchange, unsplit): {products_alone():.3f} ms per iteration", flush=True)
+if os.environ.get("PEER", "0") != "0":
+    N_.check(eng.lib.pdlp_peer_connect(eng.h, 0, W, None, N_.PEER_LOOPBACK), "pdlp_peer_connect")
+    eng.set_exchange_chunks(1)
+    for on, local_first in ((True, False), (True, True), (False, False)):
+        eng.set_peer_exchange(on)
+        eng.set_option(N_.OPT_PEER_LOCAL_FIRST, int(local_first))
+        if not on:
+            ag_ms = float(os.environ.get("AG_LIST", str(ag_ms)).split(",")[0])
+        best = min(timed(iters) for _ in range(3))
+        what = (f"direct exchange, loopback (stores into {W - 1} scratch blocks, signal + wait kernels, one stream; "
+                f"{'own-block panels between signal and wait' if local_first else 'signal, wait, whole product'})") if on else \
+               f"the same handle on the loop, all-gather {ag_ms:.2f} ms, 1 piece"
+        print(f"   {what}: {best:.3f} ms per iteration = {best / 2:.3f} per half-step -> {1e3 / best:.0f} it/s   "
+              f"(host issue time {enqueue_ms[0]:.3f} ms per iteration)", flush=True)
+    assert eng.peer_status()["gave_up_on"] is None
+    N_.check(eng.lib.pdlp_peer_close(eng.h), "pdlp_peer_close")
+    eng.peer_on = False
 for ags in [float(v) for v in os.environ.get("AG_LIST", str(ag_ms)).split(",")]:
     ag_ms = ags
     for ch in [int(v) for v in os.environ.get("CHUNKS", "1,2").split(",") if v]:

@@ -342,6 +342,7 @@ struct pdlp_solver {
         bool enabled = true;      // PDLP_OPT_PEER_EXCHANGE: pdlp_iterate uses it
         bool active = false;      // inside iterate_peer: the half-steps' epilogues store into the peers
         bool loopback = false;    // timing stand-in: the "peers" are scratch buffers of this process
+        bool local_first = false; // PDLP_OPT_PEER_LOCAL_FIRST: the own block's panels are multiplied between signal and wait
         int rank = 0, world = 1, n = 0;      // n = world - 1 peers
         void* opened[2 * MAX_PEER] = {};     // what hipIpcCloseMemHandle wants back
         int nopened = 0;
@@ -1740,6 +1741,7 @@ int pdlp_set_option(pdlp_handle h, int option, int64_t value)
             return (value != 0 && !h->graph_ok) ? PDLP_ERR_STATE : PDLP_OK;
         case PDLP_OPT_BEGIN_INLINE: h->begin_inline = value != 0; return PDLP_OK;
         case PDLP_OPT_PEER_EXCHANGE: h->peer.enabled = value != 0; return PDLP_OK;
+        case PDLP_OPT_PEER_LOCAL_FIRST: h->peer.local_first = value != 0; return PDLP_OK;
         case PDLP_OPT_PEER_TIMEOUT_MS:
             if (value < 1 || value > 3600000) return PDLP_ERR_INVALID;
             h->peer.limit_ticks = (long long)value * 100000;            // (the wait kernel counts a 100 MHz clock)
@@ -2094,24 +2096,40 @@ int peer_signal(pdlp_handle h, bool with_sums)
     sg.own_sums = (double*)(P.box + BOX_SUMS_AT) + (size_t)P.rank * BOX_SUMS_STRIDE;
     sg.n = P.n;
     sg.seq = ++P.seq;
-    hipLaunchKernelGGL(k_peer_signal, dim3(1), dim3(64), 0, h->stream, sg, with_sums ? (const double*)h->red : (const double*)nullptr);
+    if (!with_sums)
+        hipLaunchKernelGGL(k_peer_signal, dim3(1), dim3(64), 0, h->stream, sg);
+    else if (h->p.dtype == PDLP_F32)      // (pdlp_adaptive_reduce and the signal in one launch)
+        hipLaunchKernelGGL(k_adaptive_reduce_signal<float>, dim3(1), dim3(BLOCK), 0, h->stream, h->partA, h->last_gridA, h->partB,
+                           h->last_gridB, h->red, h->sc, sg);
+    else
+        hipLaunchKernelGGL(k_adaptive_reduce_signal<double>, dim3(1), dim3(BLOCK), 0, h->stream, h->partA, h->last_gridA, h->partB,
+                           h->last_gridB, h->red, h->sc, sg);
     HIP_TRY(hipGetLastError());
     return PDLP_OK;
 }
 
-// the handle's stream waits until every peer has signalled the exchange just signalled by this rank (bounded: k_peer_wait)
-int peer_wait(pdlp_handle h)
+// the handle's stream waits until every peer has signalled the exchange just signalled by this rank (bounded: k_peer_wait);
+// then_update: the step-size rule from all ranks' sums in the same launch
+int peer_wait(pdlp_handle h, bool then_update = false)
 {
     pdlp_solver::Peer& P = h->peer;
-    hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, h->stream, (const uint32_t*)P.box, P.world, P.rank, P.seq, P.limit_ticks, P.err_dev);
+    if (!then_update)
+        hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, h->stream, (const uint32_t*)P.box, P.world, P.rank, P.seq, P.limit_ticks, P.err_dev);
+    else if (h->p.dtype == PDLP_F32)
+        hipLaunchKernelGGL(k_peer_wait_adaptive_update<float>, dim3(1), dim3(64), 0, h->stream, (const uint32_t*)P.box, P.world, P.rank, P.seq,
+                           P.limit_ticks, P.err_dev, h->sc, h->red);
+    else
+        hipLaunchKernelGGL(k_peer_wait_adaptive_update<double>, dim3(1), dim3(64), 0, h->stream, (const uint32_t*)P.box, P.world, P.rank, P.seq,
+                           P.limit_ticks, P.err_dev, h->sc, h->red);
     HIP_TRY(hipGetLastError());
     return PDLP_OK;
 }
 
 // The iterations of a sharded problem WITHOUT collectives: a half-step's epilogue stores its block of xbar / y (delta mode: of the
 // float32 differences) into every peer's copy as it computes it (PeerOut), a one-wave kernel raises this rank's flag in the peers'
-// mailboxes, the panels of the next product that meet the own block are multiplied, a one-wave kernel waits for the peers' flags,
-// and the rest of the product follows.  The step-size rule's three sums travel with the flag of the y exchange and are added in rank
+// mailboxes, a one-wave kernel waits for the peers' flags, and the next product follows (PDLP_OPT_PEER_LOCAL_FIRST: split, the panels
+// that meet the own block between signal and wait -- cover for ranks that finish at different times, at the price of a launch that
+// cannot fill the chip: the own block is 1/world of the panels).  The step-size rule's three sums travel with the flag of the y exchange and are added in rank
 // order by every rank.  One stream, no events; per half-step the exchange adds two launches of a few microseconds to the critical
 // path (tools/src/ipc_probe.hip: 5.8 us for the pair between two processes) where an all-gather adds its whole duration.
 // Same arithmetic as iterate_sharded / PdlpEngine.iterate: identical bits in fixed-step mode; in adaptive mode up to the order in
@@ -2122,7 +2140,6 @@ int iterate_peer(pdlp_handle h, int iters, int adaptive)
     pdlp_solver::Peer& P = h->peer;
     if (h->delta && iters > 0 && !h->anchors_valid) return PDLP_ERR_STATE;       // (the caller refreshes the anchors: that needs gathers)
     if (iters == 0) return PDLP_OK;
-    const bool f32 = h->p.dtype == PDLP_F32;
     // entry handshake: a peer's first block may only arrive once this rank's stream has reached the iterations -- whatever this rank
     // did with its vectors before (a restart check, a restart) is behind the flag
     if ((rc = peer_signal(h, false)) != PDLP_OK || (rc = peer_wait(h)) != PDLP_OK) return rc;
@@ -2132,18 +2149,12 @@ int iterate_peer(pdlp_handle h, int iters, int adaptive)
     for (int it = 0; it < iters && rc == PDLP_OK; ++it) {
         if ((rc = pdlp_primal_half(h, adaptive)) != PDLP_OK) break;              // stores xbar (x+ - x) into the peers
         if ((rc = peer_signal(h, false)) != PDLP_OK) break;
-        if ((rc = pdlp_dual_half_begin(h, adaptive)) != PDLP_OK) break;          // K's panels over the own block of xbar
+        if (P.local_first && (rc = pdlp_dual_half_begin(h, adaptive)) != PDLP_OK) break;      // K's panels over the own block of xbar
         if ((rc = peer_wait(h)) != PDLP_OK) break;
         if ((rc = pdlp_dual_half(h, adaptive)) != PDLP_OK) break;                // stores the new y (y+ - y) into the peers
-        if (adaptive && (rc = pdlp_adaptive_reduce(h)) != PDLP_OK) break;        // this rank's three sums -> red
-        if ((rc = peer_signal(h, adaptive != 0)) != PDLP_OK) break;
-        if (it + 1 < iters && (rc = pdlp_primal_half_begin(h)) != PDLP_OK) break;
-        if ((rc = peer_wait(h)) != PDLP_OK) break;
-        if (adaptive) {
-            const double* sums = (const double*)(P.box + BOX_SUMS_AT);
-            if (f32) hipLaunchKernelGGL(k_adaptive_update_peer<float>, dim3(1), dim3(1), 0, h->stream, h->sc, h->red, sums, P.world);
-            else hipLaunchKernelGGL(k_adaptive_update_peer<double>, dim3(1), dim3(1), 0, h->stream, h->sc, h->red, sums, P.world);
-        }
+        if ((rc = peer_signal(h, adaptive != 0)) != PDLP_OK) break;              // (adaptive: this rank's three sums travel with the flag)
+        if (P.local_first && it + 1 < iters && (rc = pdlp_primal_half_begin(h)) != PDLP_OK) break;
+        if ((rc = peer_wait(h, adaptive != 0)) != PDLP_OK) break;                // (adaptive: and the rule from all ranks' sums)
     }
     P.active = false;
     h->begin_inline = saved_inline;

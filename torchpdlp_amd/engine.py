@@ -192,7 +192,7 @@ class PdlpEngine:
         # the exchange inside the library (one C call per restart period) is opt-in: PDLP_LIB_COMM=1 here, or
         # enable_library_comm() by the caller (bench.py does); the default is the torch.distributed loop of iterate()
         self.lib_comm, self.lib_comm_log = False, []
-        self.peer_on, self.peer_log = False, []          # direct exchange over HIP IPC (enable_peer_exchange)
+        self.peer_on, self.peer_log, self.peer_local_first = False, [], False     # direct exchange over HIP IPC (enable_peer_exchange)
         if self.comm is not None and self.comm.backend == "nccl" and tiles and os.environ.get("PDLP_LIB_COMM", "0") == "1":
             self.enable_library_comm()
 
@@ -437,7 +437,7 @@ class PdlpEngine:
         return True
 
     # ---- direct exchange (pdlp_peer_*): iterations without collectives ------------------------------------------------------
-    def enable_peer_exchange(self, cross_check: bool = True, timeout_ms: Optional[int] = None) -> bool:
+    def enable_peer_exchange(self, cross_check: bool = True, timeout_ms: Optional[int] = None, local_first: bool = False) -> bool:
         """Connect the ranks' handles over HIP IPC (``pdlp_peer_export`` / ``pdlp_peer_connect``, include/pdlp_hip.h): ``iterate`` then
         is ONE library call per restart period with NO collective in it -- every half-step stores its block of the exchanged vector
         straight into the other ranks' memory (xGMI between the GPUs of a node) and a flag follows; the step-size rule's sums travel
@@ -445,7 +445,9 @@ class PdlpEngine:
         connect, and (``cross_check``) two fixed-step iterations that must equal the torch.distributed loop bit for bit plus two
         adaptive ones that must agree to 1e-5 (the ranks' three sums are added in rank order here, in the collective's order there;
         identical for two ranks).  Any failure leaves all ranks where they were.  Call before the iterate is set (the cross-check
-        overwrites it and resets it to zero).  ``self.peer_log`` records what happened.  Returns whether the direct exchange is on."""
+        overwrites it and resets it to zero).  ``self.peer_log`` records what happened.  Returns whether the direct exchange is on.
+        ``local_first``: split products with the own block's panels between signal and wait (``PDLP_OPT_PEER_LOCAL_FIRST``; the
+        cross-check always runs in that form -- it is the one whose partial sums are grouped like the loop's)."""
         if self.comm is None or not hasattr(self.comm, "dist"):
             return False
         dist, group = self.comm.dist, self.comm.group
@@ -494,7 +496,12 @@ class PdlpEngine:
                 self.disable_peer_exchange()
                 return False
             log.append("cross-check: 2 fixed-step iterations bit-identical, 2 adaptive ones within 1e-5 of the torch.distributed loop")
+        self.set_peer_local_first(local_first)
         return True
+
+    def set_peer_local_first(self, on: bool):
+        self.peer_local_first = bool(on)
+        self.set_option(N.OPT_PEER_LOCAL_FIRST, int(bool(on)))
 
     def disable_peer_exchange(self):
         self.peer_on = False
@@ -524,6 +531,7 @@ class PdlpEngine:
         ok = True
         saved_lib = self.lib_comm
         self.lib_comm = False
+        self.set_peer_local_first(True)
         for adaptive in (False, True):
             out = []
             for peer in (False, True):
