@@ -155,6 +155,10 @@ def parse(argv=None):
     p.add_argument("--lib-comm", choices=["auto", "off"], default="auto",
                    help="N > 1 under RCCL: try the exchange inside the library (cross-checked against the torch.distributed loop, "
                         "falls back on any difference) or stay on the torch.distributed loop")
+    p.add_argument("--direct-exchange", choices=["auto", "off"], default="auto",
+                   help="N > 1 (2..8 ranks of one node): try the direct exchange -- the half-steps store their blocks into the other "
+                        "ranks' memory over HIP IPC / xGMI, no collective in the iteration (pdlp_peer_*); cross-checked against the "
+                        "torch.distributed loop, adopted only if faster")
     p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=40)
     # (under `python -m torch.distributed.run ... bench.py` use the long spellings or the environment: that launcher's parser
@@ -536,6 +540,48 @@ def library_phase(out: dict, exchange: dict, eng, steps: int, timed_region, norm
     deadman.disarm()
 
 
+def peer_phase(out: dict, exchange: dict, eng, steps: int, timed_region, norm_elapsed: float, rank: int, first_region_s: float = 0.0) -> bool:
+    """N > 1, AFTER the headline was measured on the torch.distributed loop: connect the ranks' handles over HIP IPC (the direct
+    exchange, pdlp_peer_*: the half-steps store their blocks straight into the other ranks' memory, no collective in the iteration),
+    cross-check it against that loop (two fixed-step iterations bit for bit, two adaptive ones to 1e-5) and repeat the timed region on
+    it.  Nothing in it can block for long -- IPC calls fail rather than hang, every wait kernel gives up after its timeout -- but it
+    runs under the watchdog all the same.  Returns whether the direct exchange became the headline."""
+    deadline = 240.0 + 3.0 * float(first_region_s)
+    snapshot = json.dumps(dict(out, config=dict(out["config"], exchange=dict(
+        exchange, path=f"torch.distributed loop (direct exchange abandoned by the watchdog after {deadline:.0f} s)"))))
+    deadman = Deadman(rank)
+    deadman.arm(deadline, lambda: snapshot, "the direct-exchange phase hung")
+    adopted = False
+    try:
+        on = eng.enable_peer_exchange(cross_check=True, timeout_ms=int(os.environ.get("PDLP_PEER_TIMEOUT_MS", "20000")))
+        exchange["direct_log"] = list(getattr(eng, "peer_log", []))
+        if on:
+            reg2 = timed_region()
+            eng._peer_check()
+            v1, v2 = steps / norm_elapsed, steps / reg2["norm_elapsed"]
+            exchange["torch_loop_value"], exchange["direct_exchange_value"] = round(v1, 3), round(v2, 3)
+            if v2 >= v1:
+                adopted = True
+                exchange["path"] = "direct exchange (pdlp_peer_*: blocks stored into the peers over HIP IPC, no collective in the iteration)"
+                out["value"], out["ms_per_step"] = round(v2, 3), round(reg2["norm_elapsed"] / steps * 1e3, 4)
+                out["timing"].update(elapsed_s=round(reg2["elapsed"], 6), raw_value=round(steps / reg2["elapsed"], 3),
+                                     checks_in_timed_region=reg2["checks_in"], restarts_in_timed_region=reg2["restarts_in"],
+                                     check_ms=round(reg2["check_s"] * 1e3, 3), normalised_elapsed_s=round(reg2["norm_elapsed"], 6))
+            else:
+                exchange["direct_exchange"] = "works and passes the cross-check, but was slower here"
+                eng.set_peer_exchange(False)
+        else:
+            exchange["direct_exchange"] = "declined"
+    except Exception as e:
+        exchange["direct_exchange"] = f"failed: {type(e).__name__}: {e}"[:200]
+        try:
+            eng.set_peer_exchange(False)
+        except Exception:
+            pass
+    deadman.disarm()
+    return adopted
+
+
 def _imports():
     """torch and the package, only in a process that is going to compute (after the decision to spawn ranks)"""
     global torch, tp, N, PdhgDriver, estimate_sigma
@@ -726,7 +772,14 @@ def main(argv=None):
         except Exception as e:
             out["timing"]["phases"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         deadman.disarm()
-        if args.lib_comm == "auto" and comm.backend == "nccl":
+        direct = False
+        # (also in the one-GPU rehearsal -- PDLP_BENCH_SHARE_GPU=1, gloo through the host: HIP IPC between processes on one card is
+        # the same code path)
+        if args.direct_exchange == "auto" and world <= 8 and (comm.backend == "nccl" or os.environ.get("PDLP_BENCH_SHARE_GPU") == "1"):
+            direct = peer_phase(out, exchange, eng, args.steps, timed_region, norm_elapsed, rank, first_region_s=first_region_s)
+        if direct:
+            exchange["library"] = "not tried: the direct exchange is the headline"
+        elif args.lib_comm == "auto" and comm.backend == "nccl":
             # (chunked exchanges too since round 5: the library's form of them -- grouped in-place broadcasts on its communication
             # stream, the pieces behind the rows they are made of -- runs on real RCCL in tests/test_distributed.py::
             # test_rccl_world1_library_communicator; the cross-check below compares it bit for bit with the torch loop first)
