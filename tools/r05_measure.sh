@@ -38,10 +38,11 @@ if [[ "$what" == *neos3* ]]; then
 fi
 if [[ "$what" == *shard* ]]; then
   say "one rank's shard, whole iterations with stand-in collectives (tools/shard_iter_timing.py)"
-  (WORLD=8 AG_LIST=0.1,0.2 CHUNKS=1,2 timeout -k 10 300 python3 tools/shard_iter_timing.py
-   WORLD=4 AG_LIST=0.16,0.3 CHUNKS=1,2 timeout -k 10 300 python3 tools/shard_iter_timing.py
-   WORLD=2 AG_LIST=0.31 CHUNKS=1 timeout -k 10 300 python3 tools/shard_iter_timing.py
-   WORLD=8 AG_LIST=0.1,0.2 CHUNKS=1,2 DTYPE=mixed timeout -k 10 300 python3 tools/shard_iter_timing.py) 2>&1 | grep -v amdgpu > gpurun_out/r05_shard_iter.log || say "shard failed"
+  # (PEER=1: the direct exchange in loopback first, then the loop with the stand-in collectives)
+  (PEER=1 WORLD=8 AG_LIST=0.1,0.2 CHUNKS=1,2 timeout -k 10 300 python3 tools/shard_iter_timing.py
+   PEER=1 WORLD=4 AG_LIST=0.16,0.3 CHUNKS=1,2 timeout -k 10 300 python3 tools/shard_iter_timing.py
+   PEER=1 WORLD=2 AG_LIST=0.31 CHUNKS=1 timeout -k 10 300 python3 tools/shard_iter_timing.py
+   PEER=1 WORLD=8 AG_LIST=0.1,0.2 CHUNKS=1,2 DTYPE=mixed timeout -k 10 300 python3 tools/shard_iter_timing.py) 2>&1 | grep -v amdgpu > gpurun_out/r05_shard_iter.log || say "shard failed"
   cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
   rm -rf gpurun_out/prof_r05_shard8
   WORLD=8 AG_LIST=0.1 CHUNKS=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r05_shard8 -o s -- python3 tools/shard_iter_timing.py > gpurun_out/r05_shard8_prof.log 2>&1 || say "shard profile failed"

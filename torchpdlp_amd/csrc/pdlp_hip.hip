@@ -572,13 +572,13 @@ inline PieceCtl piece_ctl(pdlp_handle h, const Schedule& s, bool product_is_laun
 }
 
 // direct exchange: where the other ranks keep vector `v` (0 xbar, 1 / 2 / 3 the y buffers, 4 gdx, 5 gdy), at this rank's block
-template <typename T> void peer_targets(pdlp_handle h, PeerOut<T>& po, int v)
+// (the half-steps pick the epilogue instantiation WITH the table only while h->peer.active: iterate_peer)
+template <typename T> void peer_targets(pdlp_handle h, PeerOut<T, true>& po, int v)
 {
-    po.n = 0;
-    if (!h->peer.active) return;
     for (int i = 0; i < h->peer.n; ++i) po.p[i] = (T*)h->peer.out[v][i];
     po.n = h->peer.n;
 }
+template <typename T> void peer_targets(pdlp_handle, PeerOut<T, false>&, int) {}
 
 template <typename T> T* xloc(pdlp_handle h, int ix) { return (T*)h->xb[ix] + h->p.col0; }
 template <typename T> T* yloc(pdlp_handle h, int ix) { return (T*)h->yb[ix] + h->p.row0; }
@@ -593,9 +593,25 @@ template <typename T, class Epi> int primal_from_kty(pdlp_handle h, int src, Epi
     return PDLP_OK;
 }
 
+template <typename T, bool ADAPT, bool PEER> int primal_half_e(pdlp_handle h, int src, T* ksum, const PieceCtl& pc)
+{
+    PrimalEpi<T, ADAPT, PEER> e{xloc<T>(h, h->ix_cur), xloc<T>(h, h->ix_prev), (T*)h->xbar + h->p.col0, (const T*)h->p.c,
+                                (const T*)h->p.l, (const T*)h->p.u, (T*)h->x_sum, h->sc, ksum};
+    peer_targets(h, e.peer, 0);
+    if (src >= 0) {
+        if (ADAPT) h->last_gridA = h->nl > 0 ? grid_for(h->nl) : 0;
+        return primal_from_kty<T>(h, src, e);
+    }
+    if (ADAPT) h->last_gridA = grid_of(h->sKT, h->nl);
+    h->use_split = true;
+    const int rc = launch_csr<T>(h, true, h->yb[h->ix_cur], e, h->partA);
+    h->use_split = false;
+    if (pc.finish) h->sKT.pending = false;
+    return rc;
+}
+
 template <typename T> int primal_half_t(pdlp_handle h, int adaptive)
 {
-    const double* sc = h->sc;
     // K'y of the current iterate may still be there from the restart check (of the current iterate if nothing moved
     // since, or of the candidate the restart adopted)
     const int src = (h->no_kty_reuse || h->graph_ok || h->sKT.pending) ? -1 : (h->kty_cur >= 0 ? h->kty_cur : (h->cand_valid[0] ? 0 : -1));
@@ -605,30 +621,9 @@ template <typename T> int primal_half_t(pdlp_handle h, int adaptive)
     T* ksum = (h->since_reset > 0 && !h->kty_tail_done && !h->sums_broken && !h->no_running && !h->graph_ok) ? (T*)h->kty_sum : nullptr;
     const PieceCtl pc = piece_ctl(h, h->sKT, src < 0);
     if (pc.skip) return PDLP_OK;                             // (all of this half-step went out with piece 0)
-    if (adaptive) {
-        PrimalEpi<T, true> e{xloc<T>(h, h->ix_cur), xloc<T>(h, h->ix_prev), (T*)h->xbar + h->p.col0, (const T*)h->p.c,
-                             (const T*)h->p.l, (const T*)h->p.u, (T*)h->x_sum, sc, ksum};
-        peer_targets(h, e.peer, 0);
-        if (src >= 0) {
-            h->last_gridA = h->nl > 0 ? grid_for(h->nl) : 0;
-            return primal_from_kty<T>(h, src, e);
-        }
-        h->last_gridA = grid_of(h->sKT, h->nl);
-        h->use_split = true;
-        const int rc = launch_csr<T>(h, true, h->yb[h->ix_cur], e, h->partA);
-        h->use_split = false;
-        if (pc.finish) h->sKT.pending = false;
-        return rc;
-    }
-    PrimalEpi<T, false> e{xloc<T>(h, h->ix_cur), xloc<T>(h, h->ix_prev), (T*)h->xbar + h->p.col0, (const T*)h->p.c,
-                          (const T*)h->p.l, (const T*)h->p.u, (T*)h->x_sum, sc, ksum};
-    peer_targets(h, e.peer, 0);
-    if (src >= 0) return primal_from_kty<T>(h, src, e);
-    h->use_split = true;
-    const int rc = launch_csr<T>(h, true, h->yb[h->ix_cur], e, h->partA);
-    h->use_split = false;
-    if (pc.finish) h->sKT.pending = false;
-    return rc;
+    // (inside the direct exchange the epilogue also stores xbar into the peers: its own instantiations)
+    if (h->peer.active) return adaptive ? primal_half_e<T, true, true>(h, src, ksum, pc) : primal_half_e<T, false, true>(h, src, ksum, pc);
+    return adaptive ? primal_half_e<T, true, false>(h, src, ksum, pc) : primal_half_e<T, false, false>(h, src, ksum, pc);
 }
 
 template <typename T> int refresh_kx_t(pdlp_handle h)
@@ -636,6 +631,18 @@ template <typename T> int refresh_kx_t(pdlp_handle h)
     StoreEpi<T> e{(T*)h->kxb[0]};
     int rc = launch_csr<T>(h, false, h->xb[h->ix_cur], e, h->partB);
     if (rc == PDLP_OK) h->kx_valid = true;
+    return rc;
+}
+
+template <typename T, bool ADAPT, bool PEER> int dual_half_e(pdlp_handle h, T* ksum)
+{
+    DualEpi<T, ADAPT, PEER> e{yloc<T>(h, h->ix_cur), yloc<T>(h, h->ix_prev), (const T*)h->p.q, (T*)h->y_sum, (T*)h->kxb[0],
+                              h->sc, h->ineq_end, ksum};
+    peer_targets(h, e.peer, 1 + h->ix_prev);
+    if (ADAPT) h->last_gridB = grid_of(h->sK, h->ml);
+    h->use_split = true;
+    const int rc = launch_csr<T>(h, false, h->xbar, e, h->partB);
+    h->use_split = false;
     return rc;
 }
 
@@ -648,21 +655,11 @@ template <typename T> int dual_half_t(pdlp_handle h, int adaptive)
     rc = PDLP_OK;
     if (pc.skip) {
         // (all of this half-step went out with piece 0)
-    } else if (adaptive) {
-        DualEpi<T, true> e{yloc<T>(h, h->ix_cur), yloc<T>(h, h->ix_prev), (const T*)h->p.q, (T*)h->y_sum, (T*)h->kxb[0],
-                           h->sc, h->ineq_end, ksum};
-        peer_targets(h, e.peer, 1 + h->ix_prev);
-        h->last_gridB = grid_of(h->sK, h->ml);
-        h->use_split = true;
-        rc = launch_csr<T>(h, false, h->xbar, e, h->partB);
+    } else if (h->peer.active) {
+        rc = adaptive ? dual_half_e<T, true, true>(h, ksum) : dual_half_e<T, false, true>(h, ksum);
     } else {
-        DualEpi<T, false> e{yloc<T>(h, h->ix_cur), yloc<T>(h, h->ix_prev), (const T*)h->p.q, (T*)h->y_sum, (T*)h->kxb[0],
-                            h->sc, h->ineq_end, ksum};
-        peer_targets(h, e.peer, 1 + h->ix_prev);
-        h->use_split = true;
-        rc = launch_csr<T>(h, false, h->xbar, e, h->partB);
+        rc = adaptive ? dual_half_e<T, true, false>(h, ksum) : dual_half_e<T, false, false>(h, ksum);
     }
-    h->use_split = false;
     if (rc != PDLP_OK) { h->sK.pending = false; return rc; }
     if (!pc.finish) return PDLP_OK;                          // (more pieces of this half-step to come)
     h->sK.pending = false;
@@ -944,19 +941,19 @@ template <class Epi> int delta_vector_pass(pdlp_handle h, int64_t rows, const do
     return PDLP_OK;
 }
 
-template <bool ADAPT> int delta_primal_half_a(pdlp_handle h)
+template <bool ADAPT, bool PEER> int delta_primal_half_a(pdlp_handle h)
 {
     int rc;
     if (!h->anchors_valid && (rc = delta_refresh(h)) != PDLP_OK) return rc;
-    DeltaPrimalEpi<ADAPT> e{(const double*)xloc<double>(h, h->ix_cur), xloc<double>(h, h->ix_prev), h->gdx + h->p.col0, (const double*)h->p.c,
-                            (const double*)h->p.l, (const double*)h->p.u, (double*)h->x_sum, (double*)h->ktyr, h->sc};
+    DeltaPrimalEpi<ADAPT, PEER> e{(const double*)xloc<double>(h, h->ix_cur), xloc<double>(h, h->ix_prev), h->gdx + h->p.col0, (const double*)h->p.c,
+                                  (const double*)h->p.l, (const double*)h->p.u, (double*)h->x_sum, (double*)h->ktyr, h->sc};
     peer_targets(h, e.peer, 4);
     if (h->dy_folded && !h->sKT.pending) {
         // K'y of the current y is already in the anchor (a restart check folded dy in, or the anchors are fresh): vector pass
         if (h->range_sel > 0) return PDLP_OK;                // (issued piece by piece: all of it went out with piece 0)
         h->last_gridA = h->nl > 0 ? grid_for(h->nl) : 0;
         if (h->nl == 0) return PDLP_OK;
-        hipLaunchKernelGGL((k_rowsum_epilogue<float, DeltaPrimalEpi<ADAPT>>), dim3(grid_for(h->nl)), dim3(BLOCK), 0, h->stream,
+        hipLaunchKernelGGL((k_rowsum_epilogue<float, DeltaPrimalEpi<ADAPT, PEER>>), dim3(grid_for(h->nl)), dim3(BLOCK), 0, h->stream,
                            (const float*)nullptr, 0, (int64_t)0, (int)h->nl, (const float*)nullptr, e, h->partA);
         HIP_TRY(hipGetLastError());
         return PDLP_OK;
@@ -965,7 +962,7 @@ template <bool ADAPT> int delta_primal_half_a(pdlp_handle h)
     if (pc.skip) return PDLP_OK;
     h->last_gridA = grid_of(h->sKT, h->nl);
     h->use_split = true;
-    rc = launch_mat<float, float, DeltaPrimalEpi<ADAPT>>(h, true, h->gdy, e, h->partA);
+    rc = launch_mat<float, float, DeltaPrimalEpi<ADAPT, PEER>>(h, true, h->gdy, e, h->partA);
     h->use_split = false;
     if (pc.finish || rc != PDLP_OK) {
         h->sKT.pending = false;
@@ -974,17 +971,17 @@ template <bool ADAPT> int delta_primal_half_a(pdlp_handle h)
     return rc;
 }
 
-template <bool ADAPT> int delta_dual_half_a(pdlp_handle h)
+template <bool ADAPT, bool PEER> int delta_dual_half_a(pdlp_handle h)
 {
-    DeltaDualEpi<ADAPT> e{(const double*)yloc<double>(h, h->ix_cur), yloc<double>(h, h->ix_prev), h->gdy + h->p.row0, (const double*)h->p.q,
-                          (double*)h->y_sum, (double*)h->kxb[0], h->sc, h->ineq_end};
+    DeltaDualEpi<ADAPT, PEER> e{(const double*)yloc<double>(h, h->ix_cur), yloc<double>(h, h->ix_prev), h->gdy + h->p.row0, (const double*)h->p.q,
+                                (double*)h->y_sum, (double*)h->kxb[0], h->sc, h->ineq_end};
     peer_targets(h, e.peer, 5);
     const PieceCtl pc = piece_ctl(h, h->sK);
     int rc = PDLP_OK;
     if (!pc.skip) {
         h->last_gridB = grid_of(h->sK, h->ml);
         h->use_split = true;
-        rc = launch_mat<float, float, DeltaDualEpi<ADAPT>>(h, false, h->gdx, e, h->partB);
+        rc = launch_mat<float, float, DeltaDualEpi<ADAPT, PEER>>(h, false, h->gdx, e, h->partB);
         h->use_split = false;
     }
     if (rc != PDLP_OK) { h->sK.pending = false; return rc; }
@@ -998,8 +995,16 @@ template <bool ADAPT> int delta_dual_half_a(pdlp_handle h)
     return PDLP_OK;
 }
 
-int delta_primal_half(pdlp_handle h, int adaptive) { return adaptive ? delta_primal_half_a<true>(h) : delta_primal_half_a<false>(h); }
-int delta_dual_half(pdlp_handle h, int adaptive) { return adaptive ? delta_dual_half_a<true>(h) : delta_dual_half_a<false>(h); }
+int delta_primal_half(pdlp_handle h, int adaptive)
+{
+    if (h->peer.active) return adaptive ? delta_primal_half_a<true, true>(h) : delta_primal_half_a<false, true>(h);
+    return adaptive ? delta_primal_half_a<true, false>(h) : delta_primal_half_a<false, false>(h);
+}
+int delta_dual_half(pdlp_handle h, int adaptive)
+{
+    if (h->peer.active) return adaptive ? delta_dual_half_a<true, true>(h) : delta_dual_half_a<false, true>(h);
+    return adaptive ? delta_dual_half_a<true, false>(h) : delta_dual_half_a<false, false>(h);
+}
 
 // KKT sums of a candidate from the anchors: the current iterate needs at most the pending K'dy; the averaged / previous
 // iterate two float32 products over float32(candidate - current) added to the anchors
