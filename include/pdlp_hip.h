@@ -290,6 +290,7 @@ int pdlp_half_chunk(pdlp_handle h, int transpose, int chunk);
  * identical).  Delta mode: the anchors must be valid on entry (PDLP_ERR_STATE otherwise: pdlp_refresh_products needs gathers). */
 #define PDLP_PEER_INFO_BYTES 256
 #define PDLP_PEER_LOOPBACK 1
+#define PDLP_PEER_LOOPBACK_HOST 2      /* with PDLP_PEER_LOOPBACK: one stand-in peer in pinned host memory (a slow link's stand-in) */
 int pdlp_peer_export(pdlp_handle h, void* info);
 int pdlp_peer_connect(pdlp_handle h, int rank, int world, const void* infos, int flags);
 int pdlp_peer_status(pdlp_handle h, int32_t out[4]);

@@ -119,16 +119,24 @@ def products_alone():
 
 print(f"   products alone (2 half-steps, no exchange, unsplit): {products_alone():.3f} ms per iteration", flush=True)
 if os.environ.get("PEER", "0") != "0":
-    N_.check(eng.lib.pdlp_peer_connect(eng.h, 0, W, None, N_.PEER_LOOPBACK), "pdlp_peer_connect")
-    eng.set_exchange_chunks(1)
-    for on, local_first in ((True, False), (True, True), (False, False)):
+    # PEER_HOST=1: one of the stand-in peers lives in pinned host memory -- its 1/WORLD block crosses PCIe (~55 GB/s), about the time
+    # the WORLD - 1 blocks of a real exchange take over xGMI together: shows how much of a slow drain of the stores a schedule hides
+    slow = os.environ.get("PEER_HOST", "0") != "0"
+    N_.check(eng.lib.pdlp_peer_connect(eng.h, 0, W, None, N_.PEER_LOOPBACK | (N_.PEER_LOOPBACK_HOST if slow else 0)), "pdlp_peer_connect")
+    where = f"{W - 2} scratch blocks + 1 block in pinned host memory" if slow else f"{W - 1} scratch blocks"
+    # (results of the split form in 2 / 4 row-block pieces, each with its own epilogue launch on the same stream, were tried here:
+    #  0.796 / 1.120 ms per iteration against 0.668 in one piece -- in-order launches hide nothing of a store drain;
+    #  profiles/r05_multi_gpu/direct_exchange_slow_link_stand_in.log)
+    variants = [(True, False, 1), (True, True, 1), (False, False, 1)]
+    for on, local_first, pieces in variants:
         eng.set_peer_exchange(on)
         eng.set_option(N_.OPT_PEER_LOCAL_FIRST, int(local_first))
+        eng.set_exchange_chunks(pieces)
         if not on:
             ag_ms = float(os.environ.get("AG_LIST", str(ag_ms)).split(",")[0])
         best = min(timed(iters) for _ in range(3))
-        what = (f"direct exchange, loopback (stores into {W - 1} scratch blocks, signal + wait kernels, one stream; "
-                f"{'own-block panels between signal and wait' if local_first else 'signal, wait, whole product'})") if on else \
+        form = "own-block panels between signal and wait" if local_first else "signal, wait, whole product"
+        what = f"direct exchange, loopback (stores into {where}, signal + wait kernels, one stream; {form})" if on else \
                f"the same handle on the loop, all-gather {ag_ms:.2f} ms, 1 piece"
         print(f"   {what}: {best:.3f} ms per iteration = {best / 2:.3f} per half-step -> {1e3 / best:.0f} it/s   "
               f"(host issue time {enqueue_ms[0]:.3f} ms per iteration)", flush=True)

@@ -351,6 +351,7 @@ struct pdlp_solver {
         double* sums[MAX_PEER] = {};
         char* box = nullptr;                 // the own mailbox (fine-grained device memory)
         char* scratch = nullptr;             // loopback: the stand-in destinations
+        char* scratch_host = nullptr;        // PDLP_PEER_LOOPBACK_HOST: one of them in pinned host memory (a slow link's stand-in)
         int* err = nullptr;                  // host memory the wait kernel reports a timeout through
         int* err_dev = nullptr;
         uint32_t seq = 0;
@@ -399,6 +400,7 @@ void peer_release(pdlp_handle h)
     for (int i = 0; i < P.nopened; ++i) if (P.opened[i]) (void)hipIpcCloseMemHandle(P.opened[i]);
     if (P.box) (void)hipFree(P.box);
     if (P.scratch) (void)hipFree(P.scratch);
+    if (P.scratch_host) (void)hipHostFree(P.scratch_host);
     if (P.err) (void)hipHostFree(P.err);
     (void)hipGetLastError();
     P = pdlp_solver::Peer();
@@ -2256,9 +2258,17 @@ int pdlp_peer_connect(pdlp_handle h, int rank, int world, const void* infos, int
         // process, every flag lands in the own mailbox (the waits pass at once).  What it prices: the stores and the two launches.
         const size_t blk = (size_t)(h->nl > h->ml ? h->nl : h->ml) * 8;
         HIP_TRY(hipMalloc((void**)&P.scratch, blk * (size_t)(world - 1)));
+        char* slow = nullptr;
+        if (flags & PDLP_PEER_LOOPBACK_HOST) {
+            // the first "peer" lives in pinned host memory: its block crosses PCIe (~55 GB/s: 5 MB in ~0.09 ms), about what the seven
+            // blocks of an 8-rank exchange take over xGMI together -- so the loopback also shows how much of a slow drain of the
+            // stores a schedule hides
+            HIP_TRY(hipHostMalloc((void**)&P.scratch_host, blk, hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer((void**)&slow, P.scratch_host, 0));
+        }
         for (int q = 0, i = 0; q < world; ++q) {
             if (q == rank) continue;
-            for (int v = 0; v < 6; ++v) P.out[v][i] = P.scratch + blk * (size_t)i;
+            for (int v = 0; v < 6; ++v) P.out[v][i] = (i == 0 && slow) ? slow : P.scratch + blk * (size_t)i;
             P.flag[i] = (uint32_t*)P.box + (size_t)q * BOX_FLAG_STRIDE;
             P.sums[i] = (double*)(P.box + BOX_SUMS_AT) + (size_t)q * BOX_SUMS_STRIDE;
             ++i;
