@@ -1361,6 +1361,81 @@ class _OneOfEight:
         pass
 
 
+class _AloneOfFour(_OneOfEight):
+    """rank `rank` of 4 whose peers never say anything: every collective leaves the buffers as they are"""
+    world = 4
+
+    def all_gather_async(self, full):
+        return None
+
+    def all_gather_piece(self, full, lo, hi):
+        return None
+
+    def all_reduce_sum_async(self, t):
+        return None
+
+
+@pytest.mark.parametrize("tiled", ["0", "1"])
+def test_direct_exchange_loopback_and_argument_checks(monkeypatch, tiled):
+    """pdlp_peer_* on one process: what the entry points refuse, and the loopback form (PDLP_PEER_LOOPBACK: the peers are scratch
+    blocks, the flags land in the own mailbox) against the loop whose collectives do nothing -- one rank alone either way, so the
+    same bits: signal / wait kernels, the step-size rule from the mailbox, the stores beside the epilogue's own"""
+    import ctypes as C
+    from torchpdlp_amd.distributed import shard_arrays
+    monkeypatch.setenv("PDLP_TILED", tiled)
+    if tiled == "1":
+        monkeypatch.setenv("PDLP_TILE_LW", "13")
+    lp = gen_lp(330_000, 300_000, 4, seed=12, device=DEV, recipe="mixed")
+    K = tp.CsrPair(lp.m, lp.n, lp.rowptr, lp.colidx, lp.val)
+    whole = tp.PdlpEngine.from_full(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq)
+    info, st = (C.c_char * N.PEER_INFO_BYTES)(), (C.c_int32 * 4)()
+    assert whole.lib.pdlp_peer_export(whole.h, info) == -3                       # not sharded: nothing to exchange
+    assert whole.lib.pdlp_peer_connect(whole.h, 0, 4, None, N.PEER_LOOPBACK) == -1
+    W, rank = 4, 1
+    args = shard_arrays(K, lp.c, lp.q, lp.l, lp.u, lp.m_ineq, rank, W)
+    part = args.pop("part")
+    mk = lambda: tp.PdlpEngine(comm=_AloneOfFour(rank), **args)
+    e0, e1 = mk(), mk()
+    lib, h = e1.lib, e1.h
+    assert lib.pdlp_peer_export(h, info) == 0
+    assert lib.pdlp_peer_connect(h, rank, 9, info, 0) == -1 and lib.pdlp_peer_connect(h, 0, W, info, 0) == -1      # ranks, block position
+    assert lib.pdlp_peer_connect(h, rank, W, None, 0) == -1                                                        # no infos
+    junk = bytes(N.PEER_INFO_BYTES * W)
+    assert lib.pdlp_peer_connect(h, rank, W, junk, 0) == -1 and lib.pdlp_peer_status(h, st) == 0 and st[0] == 0    # not the exporter's bytes
+    own = bytes(info.raw) * W          # the own handle cannot be opened by its own process: refused as a communication error
+    rc = lib.pdlp_peer_connect(h, rank, W, own, 0)
+    assert rc in (0, -4)
+    if rc == 0:                        # (a runtime that does open it: then it is simply connected to itself -- undo)
+        assert lib.pdlp_peer_close(h) == 0
+    assert lib.pdlp_peer_status(h, st) == 0 and st[0] == 0
+    assert lib.pdlp_peer_connect(h, rank, W, None, N.PEER_LOOPBACK) == 0
+    assert lib.pdlp_peer_connect(h, rank, W, None, N.PEER_LOOPBACK) == -3                                          # connected already
+    assert e1.peer_status() == dict(connected=True, enabled=True, gave_up_on=None, exchanges=0)
+    e1.set_option(N.OPT_PEER_LOCAL_FIRST, 1)          # (split products, as the loop runs them: the same grouping of the partial sums)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    x0 = torch.minimum(torch.maximum(torch.randn(e0.nl, device=DEV, generator=g), args["l"]), args["u"])
+    y0 = torch.randn(e0.ml, device=DEV, generator=g)
+    for adaptive in (False, True):
+        outs = []
+        for e in (e0, e1):
+            e.set_peer_exchange(e is e1)
+            e.set_iterate(x0, y0)
+            e.set_step(0.02, 1.1, 1.0, 0)
+            e.iterate(5, adaptive)
+            e.iterate(2, adaptive)
+            x, y = e.get_iterate(N.CUR)
+            outs.append((x.clone(), y.clone(), e.scalars()))
+        (xa, ya, sa), (xb, yb, sb) = outs
+        assert torch.equal(xa, xb) and torch.equal(ya, yb) and sa == sb, adaptive
+        assert float(xa.abs().sum()) > 0
+    assert e1.peer_status()["exchanges"] == 2 * (2 * 7 + 2) and e1.peer_status()["gave_up_on"] is None
+    # switched off, the connected handle iterates like the other one; closed, it is not connected
+    e1.set_peer_exchange(False)
+    assert not e1.peer_on and e1.peer_status()["connected"]
+    e1.disable_peer_exchange()
+    assert e1.peer_status() == dict(connected=False, enabled=True, gave_up_on=None, exchanges=0)
+
+
 def test_config3_one_eighth_shard_of_10Mx10M(monkeypatch, big_lp):
     """configs[3]: the 10M x 10M instance row/column-block sharded over 8 GPUs -- one rank's shard (rank 3: rows 3.75M..5M of K and
     of K') on one GPU: the split tiled product (local panels first, the others after the all-gather: pdlp_*_half_begin), the

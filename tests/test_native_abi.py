@@ -69,6 +69,11 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert lib.pdlp_probe_gather(None, 0, 10, 1, None, None) == -1
     assert lib.pdlp_trace_enable(7) == -1 and lib.pdlp_trace_enable(0) == 0
     assert lib.pdlp_range_push(None, None) == -1 and lib.pdlp_range_pop(None) == 0            # (tracing off: a pop is a no-op)
+    # the direct exchange's entry points
+    import ctypes as C
+    info, st = (C.c_char * N.PEER_INFO_BYTES)(), (C.c_int32 * 4)()
+    assert lib.pdlp_peer_export(None, info) == -1 and lib.pdlp_peer_connect(None, 0, 2, info, 0) == -1
+    assert lib.pdlp_peer_status(None, st) == -1 and lib.pdlp_peer_close(None) == -1
 
 
 def test_product_path_fails_loudly_off_the_gpu_and_without_the_library(monkeypatch, tmp_path):

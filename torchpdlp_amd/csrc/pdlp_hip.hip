@@ -2270,7 +2270,7 @@ int pdlp_peer_connect(pdlp_handle h, int rank, int world, const void* infos, int
             if (q == rank) continue;
             for (int v = 0; v < 6; ++v) P.out[v][i] = (i == 0 && slow) ? slow : P.scratch + blk * (size_t)i;
             P.flag[i] = (uint32_t*)P.box + (size_t)q * BOX_FLAG_STRIDE;
-            P.sums[i] = (double*)(P.box + BOX_SUMS_AT) + (size_t)q * BOX_SUMS_STRIDE;
+            P.sums[i] = (double*)(P.box + BOX_BYTES / 2) + (size_t)q * BOX_SUMS_STRIDE;     // (an unused part of the mailbox: the peers' slots stay zero)
             ++i;
             P.n = i;
         }
