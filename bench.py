@@ -546,7 +546,7 @@ def peer_phase(out: dict, exchange: dict, eng, steps: int, timed_region, norm_el
     cross-check it against that loop (two fixed-step iterations bit for bit, two adaptive ones to 1e-5) and repeat the timed region on
     it.  Nothing in it can block for long -- IPC calls fail rather than hang, every wait kernel gives up after its timeout -- but it
     runs under the watchdog all the same.  Returns whether the direct exchange became the headline."""
-    deadline = 240.0 + 3.0 * float(first_region_s)
+    deadline = float(os.environ.get("PDLP_PEER_PHASE_DEADLINE", 240.0 + 3.0 * float(first_region_s)))
     snapshot = json.dumps(dict(out, config=dict(out["config"], exchange=dict(
         exchange, path=f"torch.distributed loop (direct exchange abandoned by the watchdog after {deadline:.0f} s)"))))
     deadman = Deadman(rank)

@@ -278,7 +278,10 @@ int pdlp_half_chunk(pdlp_handle h, int transpose, int chunk);
  * with the flag of the y exchange and are added in rank order.  pdlp_iterate then is one call per restart period with no collective,
  * no second stream and no event in it; everything outside the iterations (KKT sums, gathers for restart checks) stays with the caller.
  *   pdlp_peer_export    this rank's PDLP_PEER_INFO_BYTES of connection data (IPC handles, offsets, shape); the caller distributes them
- *                       (an all-gather of bytes over its process group).  The workspace must lie inside ONE device allocation.
+ *                       (an all-gather of bytes over its process group).  The workspace must lie inside ONE device allocation --
+ *                       and PDLP_ERR_WORKSPACE if that allocation's size has bit 31 set (2-4 GiB, 6-8 GiB, ...): on ROCm 7.2
+ *                       hipIpcOpenMemHandle never returns for such an allocation (tools/ipc_torch_probe.py); give the workspace an
+ *                       allocation of its own of another size (PdlpEngine does: a private pool, padded to the next 4 GiB).
  *   pdlp_peer_connect   `infos` = the world x PDLP_PEER_INFO_BYTES bytes of all ranks in rank order (equal blocks, this rank's at
  *                       rank * block; at most 8 ranks).  PDLP_ERR_INVALID: shapes disagree; PDLP_ERR_COMM: a handle would not open.
  *                       flags = PDLP_PEER_LOOPBACK (infos may be null): a timing stand-in on ONE process -- the "peers" are scratch

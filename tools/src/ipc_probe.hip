@@ -53,8 +53,9 @@ __global__ void k_check(const float* buf, size_t n, float v, unsigned long long*
 
 struct Msg { hipIpcMemHandle_t big, box; unsigned long long interior, offset; };
 
-int main()
+int main(int argc, char** argv)
 {
+    // argv[1]: size of the exported allocation in MB (default 64) -- the block that is written stays 16 MB at its start
     int ab[2], ba[2];
     if (pipe(ab) || pipe(ba)) return 1;
     const pid_t pid = fork();
@@ -63,12 +64,14 @@ int main()
     CK(hipSetDevice(0));
     const size_t N = 4u << 20, OFF = (1u << 20) + 256;            // a 16 MB block at an odd interior offset of a 64 MB allocation
     char* big = nullptr;
-    CK(hipMalloc(&big, 64u << 20));
+    const size_t big_bytes = (size_t)(argc > 1 ? std::atol(argv[1]) : 64) << 20;
+    CK(hipMalloc(&big, big_bytes));
     float* mine = (float*)(big + OFF);
     unsigned* box = nullptr;
     CK(hipExtMallocWithFlags((void**)&box, 4096, hipDeviceMallocFinegrained));
     CK(hipMemset(box, 0, 4096));
     CK(hipMemset(big, 0, 64u << 20));
+    const auto t_open0 = std::chrono::steady_clock::now();
     CK(hipDeviceSynchronize());
     Msg out{}, in{};
     // (first try: hipIpcGetMemHandle(mine) -- the peer's hipIpcOpenMemHandle returns the BASE of the allocation, the interior offset is
@@ -88,7 +91,10 @@ int main()
     CK(hipIpcOpenMemHandle((void**)&their_base, in.big, hipIpcMemLazyEnablePeerAccess));
     theirs = (float*)(their_base + in.offset);
     CK(hipIpcOpenMemHandle((void**)&their_box, in.box, hipIpcMemLazyEnablePeerAccess));
-    std::printf("[%d] own block %p, peer's block opened at %p (peer's own address %#llx)\n", g_rank, (void*)mine, (void*)theirs, in.interior);
+    std::printf("[%d] own block %p, peer's block opened at %p (peer's own address %#llx); export + open of a %zu MB allocation: %.3f s\n", g_rank,
+                (void*)mine, (void*)theirs, in.interior, big_bytes >> 20,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_open0).count());
+    std::fflush(stdout);
     int* err = nullptr;
     CK(hipHostMalloc((void**)&err, 64, hipHostMallocMapped));
     *err = 0;

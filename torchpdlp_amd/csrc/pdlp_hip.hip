@@ -2179,6 +2179,7 @@ struct PeerInfo {
     int64_t vec_off[6];             // xbar, the three y buffers, gdx, gdy inside the workspace
     int64_t n, m, nl, ml;
     int32_t dtype, pid;
+    int64_t alloc_bytes;            // size of the allocation the workspace lies in (what a peer maps)
 };
 static_assert(sizeof(PeerInfo) <= PDLP_PEER_INFO_BYTES, "PeerInfo must fit its published size");
 constexpr uint32_t PEER_MAGIC = 0x50444c50u;
@@ -2229,12 +2230,16 @@ int pdlp_peer_export(pdlp_handle h, void* info)
     size_t range = 0;
     HIP_TRY(hipMemGetAddressRange(&base, &range, (hipDeviceptr_t)h->ws));
     if ((char*)h->ws + h->ws_bytes > (char*)base + range) return PDLP_ERR_WORKSPACE;   // (a workspace spanning allocations cannot be exported)
+    // ROCm 7.2: hipIpcOpenMemHandle never returns for an allocation whose size has bit 31 set (2000 / 5000 MB open at once, 3000 /
+    // 3826 / 4000 / 6500 MB hang, 4096 / 8192 / 9000 MB open: tools/ipc_torch_probe.py).  Refuse here rather than let a peer hang.
+    if (range & 0x80000000ull) return PDLP_ERR_WORKSPACE;
     HIP_TRY(hipIpcGetMemHandle(&pi.ws, (void*)base));
     HIP_TRY(hipIpcGetMemHandle(&pi.box, (void*)h->peer.box));
     pi.ws_off = h->ws - (char*)base;
     peer_vec_offsets(h, pi.vec_off);
     pi.n = h->p.n; pi.m = h->p.m; pi.nl = h->nl; pi.ml = h->ml;
     pi.dtype = h->p.dtype; pi.pid = (int32_t)getpid();
+    pi.alloc_bytes = (int64_t)range;
     std::memset(info, 0, PDLP_PEER_INFO_BYTES);
     std::memcpy(info, &pi, sizeof pi);
     return PDLP_OK;

@@ -8,6 +8,8 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
+import time
 from typing import Optional, Tuple
 
 import torch
@@ -154,7 +156,7 @@ class PdlpEngine:
                                   self.stream.cuda_stream)
         nbytes = C.c_int64(0)
         N.check(self.lib.pdlp_workspace_bytes(C.byref(self.prob), C.byref(nbytes)), "pdlp_workspace_bytes")
-        self.workspace = torch.empty(int(nbytes.value) + 256, dtype=torch.uint8, device=self.device)
+        self.workspace = self._alloc_workspace(int(nbytes.value) + 256, exportable=comm is not None)
         self._ws_off = (-self.workspace.data_ptr()) % 256
         self.h = N._H()
         N.check(self.lib.pdlp_create(C.byref(self.h), C.byref(self.prob), self.workspace.data_ptr() + self._ws_off,
@@ -455,6 +457,12 @@ class PdlpEngine:
         log = self.peer_log = []
         host_coll = dist.get_backend(group) == "gloo"
         cdev = "cpu" if host_coll else self.device
+        t_start = time.time()
+
+        def trace(what):                                         # (PDLP_PEER_TRACE=1: where a first multi-GPU run spends its time)
+            if os.environ.get("PDLP_PEER_TRACE"):
+                sys.stderr.write(f"[peer exchange, rank {rank}, {time.time() - t_start:7.2f} s] {what}\n")
+                sys.stderr.flush()
 
         def agree(ok) -> int:                                    # MIN over the ranks
             flag = torch.tensor([int(bool(ok))], dtype=torch.int32, device=cdev)
@@ -467,6 +475,8 @@ class PdlpEngine:
         nb = N.PEER_INFO_BYTES
         info = (C.c_char * nb)()
         rc = self.lib.pdlp_peer_export(self.h, info)
+        trace(f"exported (rc {rc}); the workspace ({self.workspace.numel() >> 20} MB) lies in an allocation of "
+              f"{int.from_bytes(info.raw[232:240], 'little') >> 20} MB")
         mine = torch.tensor(list(info.raw) + [int(rc == 0)], dtype=torch.uint8, device=cdev)
         every = torch.empty(world * (nb + 1), dtype=torch.uint8, device=cdev)
         dist.all_gather_into_tensor(every, mine, group=group)
@@ -475,7 +485,15 @@ class PdlpEngine:
             log.append(f"export failed on some rank (this rank: rc={rc})")
             return False
         infos = b"".join(raw[q * (nb + 1):q * (nb + 1) + nb] for q in range(world))
-        rc = self.lib.pdlp_peer_connect(self.h, rank, world, infos, 0)
+        trace("infos gathered")
+        # one rank at a time: two processes that open each other's handles at the same moment can wait for each other for ever
+        # inside hipIpcOpenMemHandle (seen on ROCm 7.2 with two ranks on one card and GB-sized workspaces)
+        rc = 0
+        for r in range(world):
+            if r == rank:
+                rc = self.lib.pdlp_peer_connect(self.h, rank, world, infos, 0)
+                trace(f"connected (rc {rc})")
+            agree(1)
         if not agree(rc == 0):
             log.append(f"connect failed on some rank (this rank: rc={rc})")
             if rc == 0:
@@ -487,10 +505,11 @@ class PdlpEngine:
         self.set_option(N.OPT_PEER_EXCHANGE, 1)
         if cross_check:
             try:
-                same = int(self._cross_check_peer())
+                same = int(self._cross_check_peer(trace=trace))
             except N.PdlpError as e:
                 log.append(f"cross-check raised: {e}")
                 same = 0
+            trace(f"cross-check done on this rank: {same}")
             if not agree(same):
                 log.append("cross-check against the torch.distributed loop differs")
                 self.disable_peer_exchange()
@@ -526,7 +545,7 @@ class PdlpEngine:
                 raise N.PdlpError(f"direct exchange: rank {st['gave_up_on']} did not signal within the timeout "
                                   f"(exchange {st['exchanges']}); the iterate of this rank is incomplete")
 
-    def _cross_check_peer(self, iters: int = 2, eta: float = 1e-2) -> bool:
+    def _cross_check_peer(self, iters: int = 2, eta: float = 1e-2, trace=lambda what: None) -> bool:
         zeros = lambda ln: torch.zeros(ln, dtype=self.dtype, device=self.device)
         ok = True
         saved_lib = self.lib_comm
@@ -538,8 +557,11 @@ class PdlpEngine:
                 self.set_peer_exchange(peer)
                 self.set_iterate(zeros(self.nl), zeros(self.ml))
                 self.set_step(eta, 1.0, 1.0, 0)
+                trace(f"cross-check: {'adaptive' if adaptive else 'fixed'}, {'direct exchange' if peer else 'loop'}: state set")
                 self.iterate(iters, adaptive)
+                trace("  iterations issued")
                 x, y = self.get_iterate(N.CUR)         # (synchronises)
+                trace("  synchronised")
                 self._peer_check()
                 out.append((x, y, self.scalars()["eta"]))
             (x0, y0, e0), (x1, y1, e1) = out
@@ -736,6 +758,10 @@ class PdlpEngine:
             return
         if h:
             self.lib.pdlp_destroy(h)
+        if getattr(self, "_ws_pool", None) is not None:        # (the block goes back before its private pool does)
+            self._views = {}
+            self.workspace = None
+            self._ws_pool = None
 
     @classmethod
     def from_full(cls, K: CsrPair, c, q, l, u, m_ineq: int, d_col=None, d_row=None, vec_dtype=None, delta=None,
@@ -765,6 +791,20 @@ class PdlpEngine:
                 v = self.workspace[off:off + ln * self.dtype.itemsize].view(self.dtype)
             self._views[key] = v
         return v
+
+    def _alloc_workspace(self, nbytes: int, exportable: bool) -> torch.Tensor:
+        """the handle's workspace.  Of a sharded engine it may be exported to the other ranks over HIP IPC (the direct exchange): it
+        then gets an allocation OF ITS OWN (a private pool of torch's allocator: a block carved out of a cached segment drags the
+        whole segment along) whose size avoids a bug of hipIpcOpenMemHandle on ROCm 7.2 -- opening an allocation whose size has bit 31
+        set (2-4 GiB, 6-8 GiB, ...) never returns (tools/ipc_torch_probe.py; pdlp_peer_export refuses such a workspace)."""
+        if not (exportable and self.device.type == "cuda" and hasattr(torch.cuda, "MemPool")):
+            return torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        size = -(-nbytes // (2 << 20)) * (2 << 20)             # (large blocks are rounded to 2 MB: ask for what will be allocated)
+        if size & 0x80000000:
+            size = (size | 0xFFFFFFFF) + 1                     # up to the next multiple of 4 GiB
+        self._ws_pool = torch.cuda.MemPool()
+        with torch.cuda.use_mem_pool(self._ws_pool, device=self.device):
+            return torch.empty(size, dtype=torch.uint8, device=self.device)
 
     def _gather(self, which: int):
         if self.comm is not None:
