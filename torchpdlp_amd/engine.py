@@ -486,8 +486,9 @@ class PdlpEngine:
             return False
         infos = b"".join(raw[q * (nb + 1):q * (nb + 1) + nb] for q in range(world))
         trace("infos gathered")
-        # one rank at a time: two processes that open each other's handles at the same moment can wait for each other for ever
-        # inside hipIpcOpenMemHandle (seen on ROCm 7.2 with two ranks on one card and GB-sized workspaces)
+        # one rank at a time (a few milliseconds each): N processes mapping each other's memory at the same moment is a first on any
+        # machine this runs on, and a rank that never returns from hipIpcOpenMemHandle is then easy to tell apart in PDLP_PEER_TRACE
+        # (the hang that did occur -- allocations with bit 31 of their size set -- is kept out by pdlp_peer_export / _alloc_workspace)
         rc = 0
         for r in range(world):
             if r == rank:
