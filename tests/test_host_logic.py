@@ -305,3 +305,22 @@ def test_driver_adaptive_retry_follows_the_references_experiment(golden, name):
     eng2.set_omega(np.float32(r["omega"]))
     drv2.advance(12)
     assert drv2.j == 12 and not np.allclose(eng2.x, eng.x)
+
+
+def test_exportable_workspace_sizes():
+    """a sharded engine's workspace may be opened by other processes over HIP IPC: its allocation avoids the sizes for which
+    hipIpcOpenMemHandle never returns on ROCm 7.2 (bit 31 of the size set: measured 3 000 / 3 826 / 4 000 / 6 500 MB hang,
+    1 700 / 2 000 / 4 096 / 5 000 / 9 000 MB open)"""
+    from torchpdlp_amd.engine import exportable_bytes
+    MB, G4 = 1 << 20, 1 << 32
+    for mb in (1, 700, 1700, 2000, 2046):                       # below 2 GiB: only rounded to 2 MB
+        assert exportable_bytes(mb * MB) == -(-mb // 2) * 2 * MB
+    for mb in (2048, 3000, 3826, 4000, 4095):                   # 2 - 4 GiB -> 4 GiB
+        assert exportable_bytes(mb * MB) == G4
+    assert exportable_bytes(G4) == G4 and exportable_bytes(G4 + 1) == G4 + 2 * MB
+    assert exportable_bytes(5000 * MB) == 5000 * MB             # 4 - 6 GiB: fine
+    assert exportable_bytes(6500 * MB) == 2 * G4                # 6 - 8 GiB -> 8 GiB
+    assert exportable_bytes(9000 * MB) == 9000 * MB
+    for n in (123, 2 ** 31 - 1, 2 ** 31, 3 * 2 ** 31 + 5, 7 * 2 ** 31):
+        s = exportable_bytes(n)
+        assert s >= n and s % (2 * MB) == 0 and not (s & 0x80000000)

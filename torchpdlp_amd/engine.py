@@ -26,6 +26,16 @@ def values_are_float32(val: torch.Tensor) -> bool:
     return val.dtype == torch.float32 or bool((val.float().to(val.dtype) == val).all())
 
 
+def exportable_bytes(nbytes: int) -> int:
+    """size of a device allocation that can hold ``nbytes`` AND be opened by another process: a multiple of 2 MB (what torch's
+    allocator makes of a large request anyway) without bit 31 -- hipIpcOpenMemHandle never returns for 2-4 GiB, 6-8 GiB, ... on
+    ROCm 7.2 (tools/ipc_torch_probe.py) -- i.e. such sizes go up to the next multiple of 4 GiB"""
+    size = -(-int(nbytes) // (2 << 20)) * (2 << 20)
+    if size & 0x80000000:
+        size = (size | 0xFFFFFFFF) + 1
+    return size
+
+
 class Comm:
     """One process per GPU.  Vectors are sharded in equal blocks (the LP is padded so the sizes divide)."""
 
@@ -800,12 +810,9 @@ class PdlpEngine:
         set (2-4 GiB, 6-8 GiB, ...) never returns (tools/ipc_torch_probe.py; pdlp_peer_export refuses such a workspace)."""
         if not (exportable and self.device.type == "cuda" and hasattr(torch.cuda, "MemPool")):
             return torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        size = -(-nbytes // (2 << 20)) * (2 << 20)             # (large blocks are rounded to 2 MB: ask for what will be allocated)
-        if size & 0x80000000:
-            size = (size | 0xFFFFFFFF) + 1                     # up to the next multiple of 4 GiB
         self._ws_pool = torch.cuda.MemPool()
         with torch.cuda.use_mem_pool(self._ws_pool, device=self.device):
-            return torch.empty(size, dtype=torch.uint8, device=self.device)
+            return torch.empty(exportable_bytes(nbytes), dtype=torch.uint8, device=self.device)
 
     def _gather(self, which: int):
         if self.comm is not None:
