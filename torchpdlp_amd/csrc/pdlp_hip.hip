@@ -39,6 +39,7 @@ constexpr int NACC = 4;          // partial sums a kernel may produce
 constexpr int MAX_CHUNKS = 4;    // chunks of the exchange of a gathered vector (sharded problems)
 constexpr int MAX_PHASE = MAX_CHUNKS + 2;
 constexpr int MAX_PEER = 7;      // direct exchange (pdlp_peer_*): the other ranks of one node
+constexpr int PEER_WAIT_BLOCKS = 8; // one waiting wave per XCD (k_peer_wait)
 // a rank's mailbox for the direct exchange (fine-grained device memory, opened by every peer): the sequence number rank q last
 // signalled, one per 64-byte line, then rank q's three sums of the step-size rule
 constexpr int BOX_BYTES = 4096, BOX_FLAG_STRIDE = 16 /* uint32 */, BOX_SUMS_AT = 1024 /* bytes */, BOX_SUMS_STRIDE = 4 /* doubles */;
@@ -2121,12 +2122,12 @@ int peer_wait(pdlp_handle h, bool then_update = false)
 {
     pdlp_solver::Peer& P = h->peer;
     if (!then_update)
-        hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, h->stream, (const uint32_t*)P.box, P.world, P.rank, P.seq, P.limit_ticks, P.err_dev);
+        hipLaunchKernelGGL(k_peer_wait, dim3(PEER_WAIT_BLOCKS), dim3(64), 0, h->stream, (const uint32_t*)P.box, P.world, P.rank, P.seq, P.limit_ticks, P.err_dev);
     else if (h->p.dtype == PDLP_F32)
-        hipLaunchKernelGGL(k_peer_wait_adaptive_update<float>, dim3(1), dim3(64), 0, h->stream, (const uint32_t*)P.box, P.world, P.rank, P.seq,
+        hipLaunchKernelGGL(k_peer_wait_adaptive_update<float>, dim3(PEER_WAIT_BLOCKS), dim3(64), 0, h->stream, (const uint32_t*)P.box, P.world, P.rank, P.seq,
                            P.limit_ticks, P.err_dev, h->sc, h->red);
     else
-        hipLaunchKernelGGL(k_peer_wait_adaptive_update<double>, dim3(1), dim3(64), 0, h->stream, (const uint32_t*)P.box, P.world, P.rank, P.seq,
+        hipLaunchKernelGGL(k_peer_wait_adaptive_update<double>, dim3(PEER_WAIT_BLOCKS), dim3(64), 0, h->stream, (const uint32_t*)P.box, P.world, P.rank, P.seq,
                            P.limit_ticks, P.err_dev, h->sc, h->red);
     HIP_TRY(hipGetLastError());
     return PDLP_OK;
