@@ -297,8 +297,11 @@ def test_user_supplied_instances(path):
     assert abs(res.objective - ref.fun) <= 2e-3 * (1 + abs(ref.fun)), (res.objective, ref.fun)
 
 
-def test_cli_sharded_over_two_ranks(tmp_path):
-    """The batch driver under a launcher (main.py:83-172 over two ranks that share this box's GPU, collectives over gloo): every rank
+@pytest.mark.parametrize("direct", [False, True])
+def test_cli_sharded_over_two_ranks(tmp_path, direct):
+    """(``direct``: with ``--direct_exchange`` -- the iterations of every instance run without collectives, the ranks' handles
+    connected over HIP IPC anew per instance; same rows.)
+    The batch driver under a launcher (main.py:83-172 over two ranks that share this box's GPU, collectives over gloo): every rank
     parses on the host and holds only its blocks; rank 0 writes the reference's CSV.  A file that fails on every rank alike (it does
     not load) gets its row and the loop goes on (the sharded run used to leave at the first failure)."""
     import shutil
@@ -318,7 +321,8 @@ def test_cli_sharded_over_two_ranks(tmp_path):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    PDLP_SHARE_GPU="1", PDLP_DIST_BACKEND="gloo", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
         procs.append(subprocess.Popen([sys.executable, "-m", "torchpdlp_amd", "--instance_path", str(inst), "--output_path", str(tmp_path / "out"),
-                                       "--adaptive_stepsize", "--primal_weight_update", "--precondition", "--seed", "3"],
+                                       "--adaptive_stepsize", "--primal_weight_update", "--precondition", "--seed", "3"]
+                                      + (["--direct_exchange", "--verbose"] if direct else []),
                                       env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert [p.returncode for p in procs] == [0, 0], outs
@@ -329,6 +333,8 @@ def test_cli_sharded_over_two_ranks(tmp_path):
     assert by["all_eq.mps"]["Status"] == "Solved"
     assert by["marker.mps"]["Objective"] == "N/A"                 # the failure row, and the run went on past it
     assert "x 2 ranks" in outs[0]
+    if direct:
+        assert outs[0].count("direct exchange: on") == 2, outs[0]           # afiro and all_eq (marker.mps never gets that far)
 
 
 def test_mixed_precision_with_ruiz_on_a_plus_minus_one_matrix():

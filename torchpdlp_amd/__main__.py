@@ -33,6 +33,10 @@ def parse_args(argv=None):
                    help="with --adaptive_stepsize: repeat a rejected step with the shrunk step size until one is accepted (the loop "
                         "the reference's adaptive step was meant to be, enhancements/test_ass.py:322-363); default: one trial, as the "
                         "live package does")
+    p.add_argument("--direct_exchange", action="store_true",
+                   help="several ranks of one node (not in the reference's CLI): iterate without collectives -- every half-step stores "
+                        "its block straight into the other ranks' memory over HIP IPC / xGMI; cross-checked against the "
+                        "collective-driven loop first, which stays in charge if anything differs")
     p.add_argument("--infeasibility_detect", action="store_true")
     p.add_argument("--verbose", action="store_true")
     p.add_argument("--support_sparse", action="store_true", help="accepted; matrices are always sparse here")
@@ -115,7 +119,8 @@ def main(argv=None) -> int:
             r = solve_lp(problem, tol=args.tolerance, precondition=args.precondition, primal_weight_update=args.primal_weight_update,
                          adaptive_stepsize=args.adaptive_stepsize, adaptive_retry=args.adaptive_retry, max_kkt=args.max_kkt, time_limit=args.time_limit,
                          verbose=args.verbose, dtype=dtype, seed=args.seed, fishnet=args.fishnet, comm=comm,
-                         infeasibility_detect=args.infeasibility_detect, precision="mixed" if args.dtype == "mixed" else None)
+                         infeasibility_detect=args.infeasibility_detect, precision="mixed" if args.dtype == "mixed" else None,
+                         direct_exchange=args.direct_exchange)
             print(f"Solver uses {r.time:.4f} seconds.\nStatus: {r.status}")
             results.append({"File": name, "Objective": f"{r.objective:.6f}", "Iterations (k)": r.iterations, "Restarts (n)": r.restarts,
                             "KKT Passes (j)": r.kkt_passes, "Time (s)": f"{r.time:.4f}", "Status": r.status})      # main.py:142-150

@@ -36,7 +36,7 @@ def solve_lp(problem: Union[str, os.PathLike, tuple], device=None, tol: float = 
              time_limit: float = 3600, verbose: bool = False, restart_period: int = 40, dtype=torch.float32,
              seed: Optional[int] = None, compat: bool = True, x_init=None, y_init=None, trace=None,
              fishnet: bool = False, comm=None, infeasibility_detect: bool = False, infeas_tol: float = 1e-4,
-             precision: Optional[str] = None, adaptive_retry: bool = False) -> LPResult:
+             precision: Optional[str] = None, adaptive_retry: bool = False, direct_exchange: bool = False) -> LPResult:
     """Solve ``min c'x, K[:m_ineq]x >= q[:m_ineq], K[m_ineq:]x = q[m_ineq:], l <= x <= u`` on the current HIP device.
 
     ``problem`` is an MPS path or ``(c, K, q, m_ineq, l, u)`` with ``K`` dense / COO / scipy-sparse / ``CsrPair``.
@@ -47,6 +47,9 @@ def solve_lp(problem: Union[str, os.PathLike, tuple], device=None, tol: float = 
     (enhancements.py:80-161) after every iteration, with its behaviour as it is.  Under ``torchrun`` (one process per GPU, process
     group initialised) pass ``comm=True``: every rank reads the same problem ON THE HOST, puts only its row blocks of K and K'
     on its GPU (the Ruiz sweeps run on the shards), and all return the full solution -- no GPU ever holds the whole LP.
+    ``direct_exchange`` (sharded solves, the ranks of ONE node, at most 8): the iterations run without collectives -- every half-step
+    stores its block straight into the other ranks' memory over HIP IPC / xGMI (``PdlpEngine.enable_peer_exchange``, DESIGN.md
+    section 5); connected and cross-checked against the collective-driven loop first, which stays in charge if anything differs.
     """
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     if precision is not None:
@@ -59,7 +62,7 @@ def solve_lp(problem: Union[str, os.PathLike, tuple], device=None, tol: float = 
         if cm.world > 1:
             return _solve_lp_sharded(problem, cm, device, tol, precondition, primal_weight_update, adaptive_stepsize, max_kkt, time_limit,
                                      verbose, restart_period, dtype, seed, compat, x_init, y_init, trace, infeasibility_detect,
-                                     infeas_tol, precision, adaptive_retry)
+                                     infeas_tol, precision, adaptive_retry, direct_exchange)
     if isinstance(problem, (str, os.PathLike)):
         c, K, q, m_ineq, l, u = mps_to_standard_form(os.fspath(problem), device=device, verbose=verbose, compat=compat, dtype=dtype)
     else:
@@ -89,7 +92,7 @@ def solve_lp(problem: Union[str, os.PathLike, tuple], device=None, tol: float = 
 
 def _solve_lp_sharded(problem, comm, device, tol, precondition, primal_weight_update, adaptive_stepsize, max_kkt, time_limit, verbose,
                       restart_period, dtype, seed, compat, x_init, y_init, trace, infeasibility_detect, infeas_tol, precision,
-                      adaptive_retry=False) -> LPResult:
+                      adaptive_retry=False, direct_exchange=False) -> LPResult:
     """``solve_lp`` over the ranks of ``comm``: the problem is read (or taken) on the host by every rank, cut into blocks balanced
     by non-zeros, and only this rank's blocks go to its GPU; Ruiz (enhancements.py:4-71) runs on the shards, the solve is
     ``run_pdlp`` on the sharded engine (pdhg.py:7-181), and every rank returns the full un-scaled solution."""
@@ -111,6 +114,10 @@ def _solve_lp_sharded(problem, comm, device, tol, precondition, primal_weight_up
     del K
     eng = engine_from_shard(sh, comm, precision=precision, precondition=precondition)
     time_used = float(getattr(eng, "ruiz_seconds", 0.0))
+    if direct_exchange:            # (every rank asks; the ranks agree on every step, and on any failure all stay on the loop)
+        on = eng.enable_peer_exchange()
+        if verbose and comm.rank == 0:
+            print("direct exchange:", "on" if on else "declined", "--", "; ".join(eng.peer_log))
     vdt = eng.dtype
     if x_init is not None and y_init is not None:          # full vectors in (of the scaled problem when preconditioned, like the
         x_init = part.pad_cols(as_vec(x_init, n, device, vdt))[eng.cols[0]:eng.cols[1]]    # one-GPU path and main.py:114-130);
