@@ -210,6 +210,85 @@ def test_a_hung_library_phase_still_prints_the_measured_line(tmp_path):
             assert r.stdout.strip() == ""
 
 
+# ---------------------------------------------------------------------------------------------------
+# the direct-exchange phase (HIP IPC between the ranks): adopted only if connected, cross-checked and faster; both of its forms are
+# timed; whatever happens, the line measured on the loop survives
+# ---------------------------------------------------------------------------------------------------
+class _PeerEng:
+    peer_log = ["peer log"]
+    peer_local_first = False
+
+    def __init__(self, behaviour):
+        self.behaviour, self.calls = behaviour, []
+
+    def enable_peer_exchange(self, cross_check, timeout_ms):
+        assert cross_check and timeout_ms > 0
+        if self.behaviour == "raise":
+            raise RuntimeError("boom")
+        return self.behaviour == "on"
+
+    def _peer_check(self):
+        self.calls.append("check")
+
+    def set_peer_local_first(self, on):
+        self.peer_local_first = bool(on)
+        self.calls.append(("local_first", bool(on)))
+
+    def set_peer_exchange(self, on):
+        self.calls.append(("exchange", bool(on)))
+
+
+def _regions(*norms):
+    it = iter(norms)
+    return lambda: dict(norm_elapsed=next(it), elapsed=0.1, checks_in=0, restarts_in=0, check_s=0.001)
+
+
+def test_peer_phase_outcomes():
+    # (behaviour, timed regions: whole-product form / own-block-first form, adopted?, value, form kept)
+    for behaviour, norms, adopted, value, first in (("off", (), False, 100.0, False), ("raise", (), False, 100.0, False),
+                                                    ("on", (0.4,), False, 100.0, False),             # slower than the loop: not adopted
+                                                    ("on", (0.1, 0.2), True, 200.0, False),          # faster; the other form is slower
+                                                    ("on", (0.1, 0.05), True, 400.0, True)):         # the other form wins
+        out, ex, eng = _line(), {"path": "torch.distributed loop"}, _PeerEng(behaviour)
+        got = bench.peer_phase(out, ex, eng, 20, _regions(*norms), 0.2, rank=0, first_region_s=0.0)
+        assert got is adopted and out["value"] == value, (behaviour, norms, ex)
+        if adopted:
+            assert "direct exchange" in ex["path"] and ex["torch_loop_value"] == 100.0 and ex["direct_log"] == ["peer log"]
+            assert ex["direct_exchange_value"] == round(20 / norms[0], 3) and ex["direct_exchange_value_own_block_first"] == round(20 / norms[1], 3)
+            assert eng.peer_local_first is first and ("own-block panels" in ex["path"]) is first
+        else:
+            assert ex["path"] == "torch.distributed loop" and "direct_exchange" in ex
+            if behaviour == "on":
+                assert ("exchange", False) in eng.calls          # the slower driver is switched off again on every rank
+
+
+def test_a_hung_peer_phase_still_prints_the_measured_line(tmp_path):
+    """a rank stuck inside hipIpcOpenMemHandle (ROCm 7.2 does that for some allocation sizes): the watchdog prints the loop's line"""
+    import subprocess
+    script = _script(tmp_path, f"""
+        import sys, time, json
+        sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+        import bench
+
+        class Eng:
+            peer_log = []
+            def enable_peer_exchange(self, cross_check, timeout_ms):
+                time.sleep(600)
+        out = {{"metric": "PDHG iterations/sec", "value": 123.0, "config": {{"workload": "w"}}, "timing": {{}}}}
+        bench.peer_phase(out, {{"path": "torch.distributed loop"}}, Eng(), 20, None, 0.2, rank=int(sys.argv[1]), first_region_s=0.0)
+        print("not reached")
+    """)
+    env = dict(os.environ, PDLP_PEER_PHASE_DEADLINE="0.5")
+    for rank, want_line in ((0, True), (1, False)):
+        r = subprocess.run([sys.executable, script, str(rank)], capture_output=True, text=True, timeout=60, env=env)
+        assert r.returncode == 0 and "not reached" not in r.stdout and "hung" in r.stderr
+        if want_line:
+            d = json.loads(r.stdout.strip())
+            assert d["value"] == 123.0 and "abandoned by the watchdog" in d["config"]["exchange"]["path"]
+        else:
+            assert r.stdout.strip() == ""
+
+
 def test_deadman_can_be_disarmed(capfd):
     import time
     dm = bench.Deadman(0)
