@@ -696,6 +696,7 @@ def _peer_worker(rank, world, port, ret, tiled):
             assert not eA.peer_on and not eA.peer_status()["connected"]
             if tiled:
                 assert all(t is not None for t in eB.tiles) and eB.split_info(0)["local_groups"] >= 1
+            loop_result = {}
             for adaptive in (True, False):
                 outs = []
                 for e in (eA, eB):
@@ -712,21 +713,25 @@ def _peer_worker(rank, world, port, ret, tiled):
                 assert torch.equal(xa, xb) and torch.equal(ya, yb), (name, adaptive)
                 assert ea == eb and ka == kb, (name, adaptive, ea, eb, ka, kb)
                 assert bool(torch.isfinite(xa).all()) and float(xa.abs().sum()) > 0
+                loop_result[adaptive] = (xa, ya, ea)
             # the default form of the direct exchange -- signal, wait, the WHOLE product: unsplit products, so for tiles the partial row
-            # sums are grouped differently (CSR: the same bits again)
+            # sums are grouped differently (CSR: the same bits again); both step rules
             eB.set_peer_local_first(False)
-            eB.set_iterate(eB.part.pad_cols(x0.to(vd))[eB.cols[0]:eB.cols[1]], eB.part.pad_rows(y0.to(vd))[eB.rows[0]:eB.rows[1]])
-            eB.set_step(0.02, 1.1, 1.0, 0)
-            eB.iterate(n1, False)
-            eB.iterate(n2, False)
-            xw, yw = eB.get_iterate(N.CUR)
-            eB._peer_check()
-            if tiled:
-                tol = 2e-4 if name == "f32" else 2e-5
-                np.testing.assert_allclose(xw.cpu().numpy(), xb.cpu().numpy(), rtol=tol, atol=tol)
-                np.testing.assert_allclose(yw.cpu().numpy(), yb.cpu().numpy(), rtol=tol, atol=tol)
-            else:
-                assert torch.equal(xw, xb) and torch.equal(yw, yb), name
+            for adaptive in (True, False):
+                eB.set_iterate(eB.part.pad_cols(x0.to(vd))[eB.cols[0]:eB.cols[1]], eB.part.pad_rows(y0.to(vd))[eB.rows[0]:eB.rows[1]])
+                eB.set_step(0.02, 1.1, 1.0, 0)
+                eB.iterate(n1, adaptive)
+                eB.iterate(n2, adaptive)
+                xw, yw = eB.get_iterate(N.CUR)
+                eB._peer_check()
+                xl, yl, el = loop_result[adaptive]
+                if tiled:
+                    tol = 2e-4 if name == "f32" else 2e-5
+                    np.testing.assert_allclose(xw.cpu().numpy(), xl.cpu().numpy(), rtol=tol, atol=tol)
+                    np.testing.assert_allclose(yw.cpu().numpy(), yl.cpu().numpy(), rtol=tol, atol=tol)
+                    np.testing.assert_allclose(eB.scalars()["eta"], el, rtol=1e-4)
+                else:
+                    assert torch.equal(xw, xl) and torch.equal(yw, yl) and eB.scalars()["eta"] == el, (name, adaptive)
             if not tiled and name == "f32":
                 # a whole restarted solve: identical restart decisions, counters and solution on both drivers
                 sols = []
