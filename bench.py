@@ -579,6 +579,10 @@ def peer_phase(out: dict, exchange: dict, eng, steps: int, timed_region, norm_el
                 out["timing"].update(elapsed_s=round(reg2["elapsed"], 6), raw_value=round(steps / reg2["elapsed"], 3),
                                      checks_in_timed_region=reg2["checks_in"], restarts_in_timed_region=reg2["restarts_in"],
                                      check_ms=round(reg2["check_s"] * 1e3, 3), normalised_elapsed_s=round(reg2["norm_elapsed"], 6))
+                ph = out["timing"].get("phases")
+                if isinstance(ph, dict) and isinstance(ph.get("product_ms"), (int, float)):
+                    # what the direct exchange leaves on the critical path of an iteration: everything but the two products
+                    ph["direct_exchange_exposed_ms"] = round(reg2["elapsed"] / steps * 1e3 - ph["product_ms"], 4)
             else:
                 exchange["direct_exchange"] = "works and passes the cross-check, but was slower here"
                 eng.set_peer_exchange(False)
