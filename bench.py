@@ -546,7 +546,7 @@ def peer_phase(out: dict, exchange: dict, eng, steps: int, timed_region, norm_el
     cross-check it against that loop (two fixed-step iterations bit for bit, two adaptive ones to 1e-5) and repeat the timed region on
     it.  Nothing in it can block for long -- IPC calls fail rather than hang, every wait kernel gives up after its timeout -- but it
     runs under the watchdog all the same.  Returns whether the direct exchange became the headline."""
-    deadline = float(os.environ.get("PDLP_PEER_PHASE_DEADLINE", 240.0 + 6.0 * float(first_region_s)))
+    deadline = float(os.environ.get("PDLP_PEER_PHASE_DEADLINE", 240.0 + 9.0 * float(first_region_s)))
     snapshot = json.dumps(dict(out, config=dict(out["config"], exchange=dict(
         exchange, path=f"torch.distributed loop (direct exchange abandoned by the watchdog after {deadline:.0f} s)"))))
     deadman = Deadman(rank)
@@ -561,20 +561,22 @@ def peer_phase(out: dict, exchange: dict, eng, steps: int, timed_region, norm_el
             v1, v2 = steps / norm_elapsed, steps / reg2["norm_elapsed"]
             exchange["torch_loop_value"], exchange["direct_exchange_value"] = round(v1, 3), round(v2, 3)
             if v2 >= v1:
-                # the other form of it: the own block's panels between signal and wait -- dearer on one GPU's loopback (a launch over
-                # 1 / world of the panels), but it hides ranks that finish at different times, which only a real run can show
-                eng.set_peer_local_first(True)
-                reg3 = timed_region()
-                eng._peer_check()
-                v3 = steps / reg3["norm_elapsed"]
-                exchange["direct_exchange_value_own_block_first"] = round(v3, 3)
-                if v3 > 1.01 * v2:
-                    v2, reg2 = v3, reg3
-                else:
-                    eng.set_peer_local_first(False)
+                # its other forms: the own block's panels between signal and wait (hides ranks that finish at different times), and
+                # the push kernel on a side stream beside those panels (hides the links where the panels are long: 2, 4 ranks) --
+                # what each is worth only a real run can show
+                best = 0
+                for form, key in ((1, "direct_exchange_value_own_block_first"), (2, "direct_exchange_value_push")):
+                    eng.set_peer_form(form)
+                    reg3 = timed_region()
+                    eng._peer_check()
+                    v3 = steps / reg3["norm_elapsed"]
+                    exchange[key] = round(v3, 3)
+                    if v3 > 1.01 * v2:
+                        v2, reg2, best = v3, reg3, form
+                eng.set_peer_form(best)
                 adopted = True
                 exchange["path"] = ("direct exchange (pdlp_peer_*: blocks stored into the peers over HIP IPC, no collective in the iteration; "
-                                    + ("own-block panels between signal and wait)" if eng.peer_local_first else "signal, wait, whole product)"))
+                                    + eng.PEER_FORMS[best] + ")")
                 out["value"], out["ms_per_step"] = round(v2, 3), round(reg2["norm_elapsed"] / steps * 1e3, 4)
                 out["timing"].update(elapsed_s=round(reg2["elapsed"], 6), raw_value=round(steps / reg2["elapsed"], 3),
                                      checks_in_timed_region=reg2["checks_in"], restarts_in_timed_region=reg2["restarts_in"],

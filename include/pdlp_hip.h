@@ -262,9 +262,15 @@ int pdlp_dual_half_piece(pdlp_handle h, int adaptive, int piece, int pieces);
  *   PDLP_OPT_PEER_TIMEOUT_MS how long a wait of the direct exchange spins before it gives up (default 10 000)
  *   PDLP_OPT_PEER_LOCAL_FIRST 0 (default): direct exchange = signal, wait, the whole product; 1: the product is split and the panels that
  *                         meet the own block run between signal and wait (they hide ranks finishing at different times but cannot
- *                         fill the chip: 1/world of the panels) -- same sums up to the grouping of the partial row sums */
+ *                         fill the chip: 1/world of the panels) -- same sums up to the grouping of the partial row sums
+ *   PDLP_OPT_PEER_PUSH    0 (default) / 1: the epilogues store locally and a copy kernel on the library's side stream carries the block
+ *                         to the peers (then the signal) WHILE the handle's stream multiplies the own block's panels -- with 2 or 4
+ *                         ranks those panels are a half / a quarter of the product and hide the transfer over the links, which
+ *                         stores issued by the epilogue (the last microseconds of a half-step, same stream) cannot; same results as
+ *                         PDLP_OPT_PEER_LOCAL_FIRST */
 enum { PDLP_OPT_RUNNING_KKT = 0, PDLP_OPT_KTY_REUSE = 1, PDLP_OPT_GRAPH = 2, PDLP_OPT_SPLIT_SLOTS = 3, PDLP_OPT_PRODUCER_PIECES = 4,
-       PDLP_OPT_BEGIN_INLINE = 5, PDLP_OPT_PEER_EXCHANGE = 6, PDLP_OPT_PEER_TIMEOUT_MS = 7, PDLP_OPT_PEER_LOCAL_FIRST = 8 };
+       PDLP_OPT_BEGIN_INLINE = 5, PDLP_OPT_PEER_EXCHANGE = 6, PDLP_OPT_PEER_TIMEOUT_MS = 7, PDLP_OPT_PEER_LOCAL_FIRST = 8,
+       PDLP_OPT_PEER_PUSH = 9 };
 int pdlp_set_option(pdlp_handle h, int option, int64_t value);
 int pdlp_exchange_plan(pdlp_handle h, int transpose, int32_t* nchunks, int64_t bounds[5]);
 int pdlp_half_chunk(pdlp_handle h, int transpose, int chunk);

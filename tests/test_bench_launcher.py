@@ -230,9 +230,12 @@ class _PeerEng:
     def _peer_check(self):
         self.calls.append("check")
 
-    def set_peer_local_first(self, on):
-        self.peer_local_first = bool(on)
-        self.calls.append(("local_first", bool(on)))
+    PEER_FORMS = ("whole product after the wait", "own-block panels between signal and wait", "push beside the own-block panels")
+    peer_form = 0
+
+    def set_peer_form(self, form):
+        self.peer_form = form
+        self.calls.append(("form", form))
 
     def set_peer_exchange(self, on):
         self.calls.append(("exchange", bool(on)))
@@ -244,18 +247,20 @@ def _regions(*norms):
 
 
 def test_peer_phase_outcomes():
-    # (behaviour, timed regions: whole-product form / own-block-first form, adopted?, value, form kept)
-    for behaviour, norms, adopted, value, first in (("off", (), False, 100.0, False), ("raise", (), False, 100.0, False),
-                                                    ("on", (0.4,), False, 100.0, False),             # slower than the loop: not adopted
-                                                    ("on", (0.1, 0.2), True, 200.0, False),          # faster; the other form is slower
-                                                    ("on", (0.1, 0.05), True, 400.0, True)):         # the other form wins
+    # (behaviour, timed regions: whole-product form / own-block-first form / push form, adopted?, value, form kept)
+    for behaviour, norms, adopted, value, form in (("off", (), False, 100.0, 0), ("raise", (), False, 100.0, 0),
+                                                   ("on", (0.4,), False, 100.0, 0),                  # slower than the loop: not adopted
+                                                   ("on", (0.1, 0.2, 0.3), True, 200.0, 0),          # faster; the other forms are slower
+                                                   ("on", (0.1, 0.05, 0.08), True, 400.0, 1),        # own-block-first wins
+                                                   ("on", (0.1, 0.09, 0.04), True, 500.0, 2)):       # the push form wins
         out, ex, eng = _line(), {"path": "torch.distributed loop"}, _PeerEng(behaviour)
         got = bench.peer_phase(out, ex, eng, 20, _regions(*norms), 0.2, rank=0, first_region_s=0.0)
         assert got is adopted and out["value"] == value, (behaviour, norms, ex)
         if adopted:
             assert "direct exchange" in ex["path"] and ex["torch_loop_value"] == 100.0 and ex["direct_log"] == ["peer log"]
             assert ex["direct_exchange_value"] == round(20 / norms[0], 3) and ex["direct_exchange_value_own_block_first"] == round(20 / norms[1], 3)
-            assert eng.peer_local_first is first and ("own-block panels" in ex["path"]) is first
+            assert ex["direct_exchange_value_push"] == round(20 / norms[2], 3)
+            assert eng.peer_form == form and _PeerEng.PEER_FORMS[form] in ex["path"]
         else:
             assert ex["path"] == "torch.distributed loop" and "direct_exchange" in ex
             if behaviour == "on":

@@ -714,9 +714,21 @@ def _peer_worker(rank, world, port, ret, tiled):
                 assert ea == eb and ka == kb, (name, adaptive, ea, eb, ka, kb)
                 assert bool(torch.isfinite(xa).all()) and float(xa.abs().sum()) > 0
                 loop_result[adaptive] = (xa, ya, ea)
+            # the push form: the epilogues store locally, a copy kernel on the side stream carries the block to the peers beside the
+            # own block's panels -- the same split products as the loop's, so the same bits
+            eB.set_peer_form(2)
+            for adaptive in (True, False):
+                eB.set_iterate(eB.part.pad_cols(x0.to(vd))[eB.cols[0]:eB.cols[1]], eB.part.pad_rows(y0.to(vd))[eB.rows[0]:eB.rows[1]])
+                eB.set_step(0.02, 1.1, 1.0, 0)
+                eB.iterate(n1, adaptive)
+                eB.iterate(n2, adaptive)
+                xp, yp = eB.get_iterate(N.CUR)
+                eB._peer_check()
+                xl, yl, el = loop_result[adaptive]
+                assert torch.equal(xp, xl) and torch.equal(yp, yl) and eB.scalars()["eta"] == el, (name, adaptive, "push")
+            eB.set_peer_form(0)
             # the default form of the direct exchange -- signal, wait, the WHOLE product: unsplit products, so for tiles the partial row
             # sums are grouped differently (CSR: the same bits again); both step rules
-            eB.set_peer_local_first(False)
             for adaptive in (True, False):
                 eB.set_iterate(eB.part.pad_cols(x0.to(vd))[eB.cols[0]:eB.cols[1]], eB.part.pad_rows(y0.to(vd))[eB.rows[0]:eB.rows[1]])
                 eB.set_step(0.02, 1.1, 1.0, 0)

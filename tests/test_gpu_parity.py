@@ -1411,12 +1411,13 @@ def test_direct_exchange_loopback_and_argument_checks(monkeypatch, tiled):
     assert lib.pdlp_peer_connect(h, rank, W, None, N.PEER_LOOPBACK) == 0
     assert lib.pdlp_peer_connect(h, rank, W, None, N.PEER_LOOPBACK) == -3                                          # connected already
     assert e1.peer_status() == dict(connected=True, enabled=True, gave_up_on=None, exchanges=0)
-    e1.set_option(N.OPT_PEER_LOCAL_FIRST, 1)          # (split products, as the loop runs them: the same grouping of the partial sums)
     g = torch.Generator(device=DEV).manual_seed(2)
     x0 = torch.minimum(torch.maximum(torch.randn(e0.nl, device=DEV, generator=g), args["l"]), args["u"])
     y0 = torch.randn(e0.ml, device=DEV, generator=g)
-    for adaptive in (False, True):
+    # (forms 1 and 2 run split products, as the loop does: the same grouping of the partial sums; 2 = the push kernel on the side stream)
+    for adaptive, form in ((False, 1), (True, 1), (False, 2), (True, 2)):
         outs = []
+        e1.set_peer_form(form)
         for e in (e0, e1):
             e.set_peer_exchange(e is e1)
             e.set_iterate(x0, y0)
@@ -1428,7 +1429,7 @@ def test_direct_exchange_loopback_and_argument_checks(monkeypatch, tiled):
         (xa, ya, sa), (xb, yb, sb) = outs
         assert torch.equal(xa, xb) and torch.equal(ya, yb) and sa == sb, adaptive
         assert float(xa.abs().sum()) > 0
-    assert e1.peer_status()["exchanges"] == 2 * (2 * 7 + 2) and e1.peer_status()["gave_up_on"] is None
+    assert e1.peer_status()["exchanges"] == 4 * (2 * 7 + 2) and e1.peer_status()["gave_up_on"] is None
     # switched off, the connected handle iterates like the other one; closed, it is not connected
     e1.set_peer_exchange(False)
     assert not e1.peer_on and e1.peer_status()["connected"]

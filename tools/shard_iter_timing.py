@@ -127,16 +127,15 @@ if os.environ.get("PEER", "0") != "0":
     # (results of the split form in 2 / 4 row-block pieces, each with its own epilogue launch on the same stream, were tried here:
     #  0.796 / 1.120 ms per iteration against 0.668 in one piece -- in-order launches hide nothing of a store drain;
     #  profiles/r05_multi_gpu/direct_exchange_slow_link_stand_in.log)
-    variants = [(True, False, 1), (True, True, 1), (False, False, 1)]
-    for on, local_first, pieces in variants:
+    variants = [(True, 0, 1), (True, 1, 1), (True, 2, 1), (False, 0, 1)]
+    for on, form, pieces in variants:
         eng.set_peer_exchange(on)
-        eng.set_option(N_.OPT_PEER_LOCAL_FIRST, int(local_first))
+        eng.set_peer_form(form)
         eng.set_exchange_chunks(pieces)
         if not on:
             ag_ms = float(os.environ.get("AG_LIST", str(ag_ms)).split(",")[0])
         best = min(timed(iters) for _ in range(3))
-        form = "own-block panels between signal and wait" if local_first else "signal, wait, whole product"
-        what = f"direct exchange, loopback (stores into {where}, signal + wait kernels, one stream; {form})" if on else \
+        what = f"direct exchange, loopback (stores into {where}, signal + wait kernels; {eng.PEER_FORMS[form]})" if on else \
                f"the same handle on the loop, all-gather {ag_ms:.2f} ms, 1 piece"
         print(f"   {what}: {best:.3f} ms per iteration = {best / 2:.3f} per half-step -> {1e3 / best:.0f} it/s   "
               f"(host issue time {enqueue_ms[0]:.3f} ms per iteration)", flush=True)

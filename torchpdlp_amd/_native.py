@@ -17,7 +17,7 @@ CUR, AVG, PREV = 0, 1, 2
 (BUF_X_CUR, BUF_X_PREV, BUF_XBAR, BUF_X_AVG, BUF_Y_CUR, BUF_Y_PREV, BUF_Y_AVG, BUF_RED, BUF_X_SUM, BUF_Y_SUM,
  BUF_SCALARS, BUF_DX, BUF_DY, BUF_LAM_PREV, BUF_GDX, BUF_GDY) = range(16)
 NRED, NSCAL = 8, 16
-OPT_RUNNING_KKT, OPT_KTY_REUSE, OPT_GRAPH, OPT_SPLIT_SLOTS, OPT_PRODUCER_PIECES, OPT_BEGIN_INLINE, OPT_PEER_EXCHANGE, OPT_PEER_TIMEOUT_MS, OPT_PEER_LOCAL_FIRST = range(9)
+OPT_RUNNING_KKT, OPT_KTY_REUSE, OPT_GRAPH, OPT_SPLIT_SLOTS, OPT_PRODUCER_PIECES, OPT_BEGIN_INLINE, OPT_PEER_EXCHANGE, OPT_PEER_TIMEOUT_MS, OPT_PEER_LOCAL_FIRST, OPT_PEER_PUSH = range(10)
 PEER_INFO_BYTES, PEER_LOOPBACK, PEER_LOOPBACK_HOST = 256, 1, 2
 # indices into the scalar block
 S_ETA, S_OMEGA, S_THETA, S_TAU, S_SIGMA, S_WPEND, S_ETASUM, S_K, S_INV1PT, S_ACCEPT, S_ETABAR, S_DEN, S_ETASUM_PREV = range(13)

@@ -344,6 +344,7 @@ struct pdlp_solver {
         bool active = false;      // inside iterate_peer: the half-steps' epilogues store into the peers
         bool loopback = false;    // timing stand-in: the "peers" are scratch buffers of this process
         bool local_first = false; // PDLP_OPT_PEER_LOCAL_FIRST: the own block's panels are multiplied between signal and wait
+        bool push = false;        // PDLP_OPT_PEER_PUSH: the block leaves by a copy kernel on the side stream, beside those panels
         int rank = 0, world = 1, n = 0;      // n = world - 1 peers
         void* opened[2 * MAX_PEER] = {};     // what hipIpcCloseMemHandle wants back
         int nopened = 0;
@@ -353,6 +354,8 @@ struct pdlp_solver {
         char* box = nullptr;                 // the own mailbox (fine-grained device memory)
         char* scratch = nullptr;             // loopback: the stand-in destinations
         char* scratch_host = nullptr;        // PDLP_PEER_LOOPBACK_HOST: one of them in pinned host memory (a slow link's stand-in)
+        hipStream_t pstream = nullptr;       // push form: a HIGH-priority stream -- the copy kernel must get its few waves onto the
+        hipEvent_t ev_push = nullptr;        //   chip before the own-block panels' launch fills every CU's registers
         int* err = nullptr;                  // host memory the wait kernel reports a timeout through
         int* err_dev = nullptr;
         uint32_t seq = 0;
@@ -402,6 +405,8 @@ void peer_release(pdlp_handle h)
     if (P.box) (void)hipFree(P.box);
     if (P.scratch) (void)hipFree(P.scratch);
     if (P.scratch_host) (void)hipHostFree(P.scratch_host);
+    if (P.pstream) { (void)hipStreamSynchronize(P.pstream); (void)hipStreamDestroy(P.pstream); }
+    if (P.ev_push) (void)hipEventDestroy(P.ev_push);
     if (P.err) (void)hipHostFree(P.err);
     (void)hipGetLastError();
     P = pdlp_solver::Peer();
@@ -1750,6 +1755,7 @@ int pdlp_set_option(pdlp_handle h, int option, int64_t value)
         case PDLP_OPT_BEGIN_INLINE: h->begin_inline = value != 0; return PDLP_OK;
         case PDLP_OPT_PEER_EXCHANGE: h->peer.enabled = value != 0; return PDLP_OK;
         case PDLP_OPT_PEER_LOCAL_FIRST: h->peer.local_first = value != 0; return PDLP_OK;
+        case PDLP_OPT_PEER_PUSH: h->peer.push = value != 0; return PDLP_OK;
         case PDLP_OPT_PEER_TIMEOUT_MS:
             if (value < 1 || value > 3600000) return PDLP_ERR_INVALID;
             h->peer.limit_ticks = (long long)value * 100000;            // (the wait kernel counts a 100 MHz clock)
@@ -2096,24 +2102,70 @@ int iterate_sharded(pdlp_handle h, int iters, int adaptive)
 // ---- direct exchange: no collective in the iteration -------------------------------------------------------------------------
 // "everything this rank has stored into your vectors up to now is complete" to every peer (and, with_sums, this rank's three sums of
 // the step-size rule): one tiny kernel behind the half-step that did the storing
-int peer_signal(pdlp_handle h, bool with_sums)
+int peer_signal(pdlp_handle h, bool with_sums, hipStream_t stream = nullptr)
 {
     pdlp_solver::Peer& P = h->peer;
+    if (!stream) stream = h->stream;
     PeerSignal sg{};
     for (int i = 0; i < P.n; ++i) { sg.flag[i] = P.flag[i]; sg.sums[i] = P.sums[i]; }
     sg.own_sums = (double*)(P.box + BOX_SUMS_AT) + (size_t)P.rank * BOX_SUMS_STRIDE;
+    sg.own_flag = (uint32_t*)P.box + (size_t)P.rank * BOX_FLAG_STRIDE;
     sg.n = P.n;
     sg.seq = ++P.seq;
     if (!with_sums)
-        hipLaunchKernelGGL(k_peer_signal, dim3(1), dim3(64), 0, h->stream, sg);
+        hipLaunchKernelGGL(k_peer_signal, dim3(1), dim3(64), 0, stream, sg);
     else if (h->p.dtype == PDLP_F32)      // (pdlp_adaptive_reduce and the signal in one launch)
-        hipLaunchKernelGGL(k_adaptive_reduce_signal<float>, dim3(1), dim3(BLOCK), 0, h->stream, h->partA, h->last_gridA, h->partB,
+        hipLaunchKernelGGL(k_adaptive_reduce_signal<float>, dim3(1), dim3(BLOCK), 0, stream, h->partA, h->last_gridA, h->partB,
                            h->last_gridB, h->red, h->sc, sg);
     else
-        hipLaunchKernelGGL(k_adaptive_reduce_signal<double>, dim3(1), dim3(BLOCK), 0, h->stream, h->partA, h->last_gridA, h->partB,
+        hipLaunchKernelGGL(k_adaptive_reduce_signal<double>, dim3(1), dim3(BLOCK), 0, stream, h->partA, h->last_gridA, h->partB,
                            h->last_gridB, h->red, h->sc, sg);
     HIP_TRY(hipGetLastError());
     return PDLP_OK;
+}
+
+// bytes per element of target vector v and the start of this rank's block in it
+size_t peer_block_start(pdlp_handle h, int v)
+{
+    const size_t esz = v >= 4 ? 4 : h->es;
+    return (size_t)(v == 0 || v == 4 ? h->p.col0 : h->p.row0) * esz;
+}
+
+// push form: behind everything the handle's stream has enqueued so far, on the side stream: this rank's block of vector v (0 xbar,
+// 1..3 the y buffers, 4 gdx, 5 gdy) into every peer's copy, then the signal (with the step-size rule's sums for the y exchange)
+int peer_push_and_signal(pdlp_handle h, int v, bool with_sums)
+{
+    pdlp_solver::Peer& P = h->peer;
+    if (!P.pstream) {
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&P.pstream, hipStreamNonBlocking, greatest));
+        HIP_TRY(hipEventCreateWithFlags(&P.ev_push, hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(P.ev_push, h->stream));
+    HIP_TRY(hipStreamWaitEvent(P.pstream, P.ev_push, 0));
+    const bool x_side = v == 0 || v == 4;
+    const int64_t len = x_side ? h->nl : h->ml;
+    const char* base = v == 0 ? h->xbar : (v == 4 ? (const char*)h->gdx : (v == 5 ? (const char*)h->gdy : h->yb[v - 1]));
+    const char* src = base + peer_block_start(h, v);
+    // (a modest grid: the copy is link-bound.  Where the own-block launch fills the chip -- 2 ranks: 502 workgroups holding every
+    //  register of every CU -- the copy only gets going when those workgroups retire, and a grid small enough for the slots they
+    //  leave is too slow to feed a link: measured, profiles/r05_multi_gpu/README.md.  The form pays at 4 ranks.)
+    const int grid = (int)((len + BLOCK - 1) / BLOCK < 128 ? (len + BLOCK - 1) / BLOCK : 128);
+    if (len > 0) {
+        if (v >= 4 || h->es == 4) {
+            PeerPush<float> d{};
+            for (int i = 0; i < P.n; ++i) d.dst[i] = (float*)P.out[v][i];
+            d.n = P.n;
+            hipLaunchKernelGGL(k_peer_push<float>, dim3(grid), dim3(BLOCK), 0, P.pstream, (const float*)src, d, len);
+        } else {
+            PeerPush<double> d{};
+            for (int i = 0; i < P.n; ++i) d.dst[i] = (double*)P.out[v][i];
+            d.n = P.n;
+            hipLaunchKernelGGL(k_peer_push<double>, dim3(grid), dim3(BLOCK), 0, P.pstream, (const double*)src, d, len);
+        }
+    }
+    return peer_signal(h, with_sums, P.pstream);
 }
 
 // the handle's stream waits until every peer has signalled the exchange just signalled by this rank (bounded: k_peer_wait);
@@ -2152,16 +2204,22 @@ int iterate_peer(pdlp_handle h, int iters, int adaptive)
     // did with its vectors before (a restart check, a restart) is behind the flag
     if ((rc = peer_signal(h, false)) != PDLP_OK || (rc = peer_wait(h)) != PDLP_OK) return rc;
     const bool saved_inline = h->begin_inline;
-    h->begin_inline = true;                       // (nothing runs beside the handle's stream: the own-block panels go onto it)
-    P.active = true;
+    h->begin_inline = true;                       // (the own-block panels go onto the handle's stream)
+    // push form: the epilogues store locally; a copy kernel on the side stream carries the block to the peers while the handle's
+    // stream multiplies the own block's panels -- where those panels are a good part of the product (2, 4 ranks) they hide the
+    // transfer, which the stores of an epilogue, issued in the last microseconds of a half-step on the same stream, cannot
+    const bool push = P.push;
+    const bool first = P.local_first || push;
+    P.active = !push;
     for (int it = 0; it < iters && rc == PDLP_OK; ++it) {
         if ((rc = pdlp_primal_half(h, adaptive)) != PDLP_OK) break;              // stores xbar (x+ - x) into the peers
-        if ((rc = peer_signal(h, false)) != PDLP_OK) break;
-        if (P.local_first && (rc = pdlp_dual_half_begin(h, adaptive)) != PDLP_OK) break;      // K's panels over the own block of xbar
+        if ((rc = push ? peer_push_and_signal(h, h->delta ? 4 : 0, false) : peer_signal(h, false)) != PDLP_OK) break;
+        if (first && (rc = pdlp_dual_half_begin(h, adaptive)) != PDLP_OK) break;              // K's panels over the own block of xbar
         if ((rc = peer_wait(h)) != PDLP_OK) break;
         if ((rc = pdlp_dual_half(h, adaptive)) != PDLP_OK) break;                // stores the new y (y+ - y) into the peers
-        if ((rc = peer_signal(h, adaptive != 0)) != PDLP_OK) break;              // (adaptive: this rank's three sums travel with the flag)
-        if (P.local_first && it + 1 < iters && (rc = pdlp_primal_half_begin(h)) != PDLP_OK) break;
+        // (adaptive: this rank's three sums travel with the flag; the new y is in the buffer that has just become current)
+        if ((rc = push ? peer_push_and_signal(h, h->delta ? 5 : 1 + h->ix_cur, adaptive != 0) : peer_signal(h, adaptive != 0)) != PDLP_OK) break;
+        if (first && it + 1 < iters && (rc = pdlp_primal_half_begin(h)) != PDLP_OK) break;
         if ((rc = peer_wait(h, adaptive != 0)) != PDLP_OK) break;                // (adaptive: and the rule from all ranks' sums)
     }
     P.active = false;
@@ -2191,13 +2249,6 @@ void peer_vec_offsets(pdlp_handle h, int64_t off[6])
     for (int i = 0; i < 3; ++i) off[1 + i] = h->yb[i] - h->ws;
     off[4] = (char*)h->gdx - h->ws;
     off[5] = (char*)h->gdy - h->ws;
-}
-
-// bytes per element of target vector v and the start of this rank's block in it
-size_t peer_block_start(pdlp_handle h, int v)
-{
-    const size_t esz = v >= 4 ? 4 : h->es;
-    return (size_t)(v == 0 || v == 4 ? h->p.col0 : h->p.row0) * esz;
 }
 
 int peer_own_resources(pdlp_handle h)

@@ -205,6 +205,7 @@ class PdlpEngine:
         # enable_library_comm() by the caller (bench.py does); the default is the torch.distributed loop of iterate()
         self.lib_comm, self.lib_comm_log = False, []
         self.peer_on, self.peer_log, self.peer_local_first = False, [], False     # direct exchange over HIP IPC (enable_peer_exchange)
+        self.peer_push, self.peer_form = False, 0
         if self.comm is not None and self.comm.backend == "nccl" and tiles and os.environ.get("PDLP_LIB_COMM", "0") == "1":
             self.enable_library_comm()
 
@@ -532,6 +533,20 @@ class PdlpEngine:
     def set_peer_local_first(self, on: bool):
         self.peer_local_first = bool(on)
         self.set_option(N.OPT_PEER_LOCAL_FIRST, int(bool(on)))
+
+    def set_peer_push(self, on: bool):
+        """``PDLP_OPT_PEER_PUSH``: the block leaves by a copy kernel on a side stream, beside the own block's panels of the next product
+        (the form for 2 and 4 ranks, where those panels are long enough to hide the links)"""
+        self.peer_push = bool(on)
+        self.set_option(N.OPT_PEER_PUSH, int(bool(on)))
+
+    PEER_FORMS = ("whole product after the wait", "own-block panels between signal and wait", "push beside the own-block panels")
+
+    def set_peer_form(self, form: int):
+        """0: signal, wait, whole product; 1: own-block panels between signal and wait; 2: push kernel beside the own-block panels"""
+        self.set_peer_local_first(form == 1)
+        self.set_peer_push(form == 2)
+        self.peer_form = int(form)
 
     def disable_peer_exchange(self):
         self.peer_on = False
