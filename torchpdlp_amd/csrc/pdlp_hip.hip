@@ -2190,7 +2190,7 @@ int peer_wait(pdlp_handle h, bool then_update = false)
 // mailboxes, a one-wave kernel waits for the peers' flags, and the next product follows (PDLP_OPT_PEER_LOCAL_FIRST: split, the panels
 // that meet the own block between signal and wait -- cover for ranks that finish at different times, at the price of a launch that
 // cannot fill the chip: the own block is 1/world of the panels).  The step-size rule's three sums travel with the flag of the y exchange and are added in rank
-// order by every rank.  One stream, no events; per half-step the exchange adds two launches of a few microseconds to the critical
+// order by every rank.  One stream, no events (the push form: a side stream for the copy kernel); per half-step the exchange adds two launches of a few microseconds to the critical
 // path (tools/src/ipc_probe.hip: 5.8 us for the pair between two processes) where an all-gather adds its whole duration.
 // Same arithmetic as iterate_sharded / PdlpEngine.iterate: identical bits in fixed-step mode; in adaptive mode up to the order in
 // which the ranks' sums are added (rank order here, the collective's order there; two ranks: identical).
